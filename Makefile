@@ -1,0 +1,41 @@
+# Build everything in-tree (the .so files travel to the GPU box with the
+# snapshot).  `make` = host scene lib + HIP lib + CPU oracle.
+#   ezrt_amd/lib/libezrt_scene.so   host C++ scene build (no HIP dependency)
+#   ezrt_amd/lib/libezrt_hip.so     hand-written gfx950 kernels + the C ABI
+#   oracle/libezrt_oracle.so        CPU oracle (test infrastructure)
+ROCM ?= /opt/rocm
+HIPCC ?= $(ROCM)/bin/hipcc
+CXX ?= g++
+ARCH ?= gfx950
+
+LIBDIR = ezrt_amd/lib
+HOST_SRC = ezrt_amd/csrc/host/scene.cpp ezrt_amd/csrc/host/hdr.cpp ezrt_amd/csrc/host/host_c_api.cpp
+HIP_SRC = ezrt_amd/csrc/hip/ezrt_hip.hip
+HIP_DEPS = $(wildcard ezrt_amd/csrc/hip/*.h) $(wildcard ezrt_amd/csrc/hip/*.hip) $(wildcard include/*)
+
+# -ffp-contract=off everywhere: the trace's discrete decisions must be
+# bit-identical between x86 and gfx950 (include/ezrt_detmath.h).
+HOST_FLAGS = -O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-math-errno -Wall -Wextra -Iinclude
+HIP_FLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math \
+            -fno-gpu-flush-denormals-to-zero -Wall -Wno-unused-function -Iinclude -Iezrt_amd/csrc/hip
+
+all: host hip oracle
+
+host: $(LIBDIR)/libezrt_scene.so
+hip: $(LIBDIR)/libezrt_hip.so
+oracle:
+	$(MAKE) -C oracle
+
+$(LIBDIR)/libezrt_scene.so: $(HOST_SRC) include/ezrt_scene.hpp include/ezrt_scene_c.h include/ezrt_detmath.h
+	@mkdir -p $(LIBDIR)
+	$(CXX) $(HOST_FLAGS) -shared -o $@ $(HOST_SRC)
+
+$(LIBDIR)/libezrt_hip.so: $(HIP_DEPS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIP_FLAGS) -shared -o $@ $(HIP_SRC)
+
+clean:
+	rm -f $(LIBDIR)/*.so
+	$(MAKE) -C oracle clean
+
+.PHONY: all host hip oracle clean

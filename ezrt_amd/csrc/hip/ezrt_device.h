@@ -1,0 +1,515 @@
+// ezrt_device.h -- device-side building blocks of the gfx950 trace: vector
+// helpers with a fixed evaluation order, RNG/Sobol, the BVH traversal over the
+// device scene layout, texture fetches, the Disney BRDF and its samplers.
+//
+// Results contract: every function here reproduces, bit for bit, the fp32
+// arithmetic the reference's fragment shader specifies once its
+// implementation-defined parts are pinned as in DESIGN.md ("arithmetic
+// contract"): left-to-right evaluation, no fma contraction (-ffp-contract=off),
+// GLSL built-ins from include/ezrt_detmath.h.  Reference lines are cited per
+// function (P5/fsh = part 5 shaders/fshader.fsh, etc.).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ezrt.h"
+#include "ezrt_detmath.h"
+
+#define EZD __device__ __forceinline__
+
+namespace ezd {
+
+constexpr float PI = EZ_PI;
+constexpr float INF = EZ_INF;
+
+struct f3 {
+  float x, y, z;
+};
+EZD f3 mk(float x, float y, float z) { return f3{x, y, z}; }
+EZD f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+EZD f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+EZD f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+EZD f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+EZD f3 operator/(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+EZD f3 operator-(f3 a) { return mk(-a.x, -a.y, -a.z); }
+EZD float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+EZD f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+EZD f3 normalize(f3 a) {
+  float inv = 1.0f / __builtin_sqrtf(dot(a, a));
+  return a * inv;
+}
+EZD f3 mix3(f3 a, f3 b, float t) { return mk(ez_mix(a.x, b.x, t), ez_mix(a.y, b.y, t), ez_mix(a.z, b.z, t)); }
+EZD f3 reflect(f3 i, f3 n) { // GLSL: I - 2.0 * dot(N, I) * N
+  float k = 2.0f * dot(n, i);
+  return i - n * k;
+}
+EZD float sqr(float x) { return x * x; }
+
+// ---------------------------------------------------------------------------
+// Device scene layout (built by ezrt_scene_create from the reference arrays).
+//
+//  tri_geom : 3 x float4 per triangle = 48 B, one cache line pair per test
+//             (p1.xyz, N.x) (p2.xyz, N.y) (p3.xyz, N.z);  N = the unit plane
+//             normal hitTriangle recomputes per call (P5/fsh:172) -- a pure
+//             function of the triangle, evaluated once with the same fp32 ops.
+//  tri_ref  : the reference's own 36-float records (144 B); only texels 3-11
+//             (vertex normals + material) are read, once per *winning* hit.
+//  inner    : 4 x float4 per inner node = 64 B: both children's boxes plus two
+//             child references, so an inner visit is ONE 64-B fetch instead of
+//             the reference's three 48-B getBVHNode calls (P5/fsh:266,281,285).
+//             ref >= 0      : index of an inner record
+//             ref bit31 set : leaf, bits 30..24 = n-1, bits 23..0 = first tri
+struct DevScene {
+  const float4* tri_geom;
+  const float* tri_ref;
+  const float4* inner;
+  uint32_t root_ref;
+  int32_t n_tri;
+  const float4* hdr;   // RGBA texels, row 0 = top
+  const float4* cache; // (x/w, y/h, pdf, 0)
+  int32_t env_w, env_h, env_filter;
+};
+
+constexpr uint32_t LEAF_BIT = 0x80000000u;
+
+struct Counters { // per-thread, registers
+  uint32_t rays, pops, inner, tris, mats, envmap, envcache;
+};
+
+// ---------------------------------------------------------------------------
+// RNG: P5/fsh:315-331
+EZD uint32_t wang_hash(uint32_t& seed) {
+  seed = (seed ^ 61u) ^ (seed >> 16);
+  seed *= 9u;
+  seed = seed ^ (seed >> 4);
+  seed *= 0x27d4eb2du;
+  seed = seed ^ (seed >> 15);
+  return seed;
+}
+EZD float rnd(uint32_t& seed) { return (float)wang_hash(seed) / 4294967296.0f; }
+
+// CranleyPattersonRotation: P5/fsh:378-396.  The offsets depend on the pixel only.
+EZD void cp_offsets(uint32_t ix, uint32_t iy, float& u, float& v) {
+  uint32_t pseed = (ix * 1973u + iy * 9277u + 59u * 26699u) | 1u;
+  u = (float)wang_hash(pseed) / 4294967296.0f;
+  v = (float)wang_hash(pseed) / 4294967296.0f;
+}
+EZD float cp_rotate(float p, float off) {
+  p += off;
+  if (p > 1.0f) p -= 1.0f;
+  if (p < 0.0f) p += 1.0f;
+  return p;
+}
+
+// ---------------------------------------------------------------------------
+// hitAABB: P5/fsh:220-233 with invdir hoisted (1.0/dir is the same value on
+// every call of one ray).
+EZD float hit_aabb(f3 S, f3 inv, f3 AA, f3 BB) {
+  f3 f = (BB - S) * inv;
+  f3 n = (AA - S) * inv;
+  float t1 = ez_min(ez_max(f.x, n.x), ez_min(ez_max(f.y, n.y), ez_max(f.z, n.z)));
+  float t0 = ez_max(ez_min(f.x, n.x), ez_max(ez_min(f.y, n.y), ez_min(f.z, n.z)));
+  return (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
+}
+
+// hitTriangle, distance part: P5/fsh:160-198.  Flipping N (fsh:175-178) negates
+// numerator, denominator and all three edge signs exactly, so t and the hit
+// decision do not depend on it; isInside is recomputed for the winner.
+EZD bool hit_triangle_t(const float4* __restrict__ g, f3 S, f3 d, float& t_out) {
+  float4 a = g[0], b = g[1], c = g[2];
+  f3 p1 = mk(a.x, a.y, a.z), p2 = mk(b.x, b.y, b.z), p3 = mk(c.x, c.y, c.z);
+  f3 N = mk(a.w, b.w, c.w);
+  float Nd = dot(N, d);
+  if (ez_abs(Nd) < 0.00001f) return false;
+  float t = (dot(N, p1) - dot(S, N)) / Nd;
+  if (t < 0.0005f) return false;
+  f3 P = S + d * t;
+  f3 c1 = cross(p2 - p1, P - p1);
+  f3 c2 = cross(p3 - p2, P - p2);
+  f3 c3 = cross(p1 - p3, P - p3);
+  float s1 = dot(c1, N), s2 = dot(c2, N), s3 = dot(c3, N);
+  bool r1 = (s1 > 0.0f) && (s2 > 0.0f) && (s3 > 0.0f);
+  bool r2 = (s1 < 0.0f) && (s2 < 0.0f) && (s3 < 0.0f);
+  t_out = t;
+  return r1 || r2;
+}
+
+// hitBVH: P5/fsh:254-306 + hitArray 238-251.  Unpruned, near-first, ties go
+// right-first, strict < keeps the first-found hit -- identical visit order per
+// ray.  The traversal stack lives in LDS: `stack` points at this lane's column
+// (stride = STRIDE ints) so bank = lane % 32 and the two half-waves never
+// conflict.  Only {t, triangle} are carried; everything else is a pure function
+// of the winner.
+template <bool FULLCTR, int STRIDE>
+EZD void hit_bvh(const DevScene& sc, f3 S, f3 d, int* __restrict__ stack, int32_t& best_tri, float& best_t,
+                 Counters& ctr) {
+  ctr.rays++;
+  best_tri = -1;
+  best_t = INF;
+  f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  int sp = 0;
+  uint32_t ref = sc.root_ref;
+  for (;;) {
+    if (FULLCTR) ctr.pops++;
+    if (ref & LEAF_BIT) {
+      int first = (int)(ref & 0x00ffffffu);
+      int n = (int)((ref >> 24) & 0x7fu) + 1;
+      float leaf_best = INF; // only for the M counter (hitArray's local res)
+      for (int i = first; i < first + n; i++) {
+        float t;
+        bool hit = hit_triangle_t(sc.tri_geom + (size_t)i * 3, S, d, t);
+        if (FULLCTR) {
+          ctr.tris++;
+          if (hit && t < leaf_best) {
+            leaf_best = t;
+            ctr.mats++;
+          }
+        }
+        if (hit && t < best_t) {
+          best_t = t;
+          best_tri = i;
+        }
+      }
+    } else {
+      if (FULLCTR) ctr.inner++;
+      const float4* r = sc.inner + (size_t)ref * 4;
+      float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
+      float d1 = hit_aabb(S, inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));
+      float d2 = hit_aabb(S, inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w));
+      uint32_t left = __float_as_uint(q3.x), right = __float_as_uint(q3.y);
+      if (d1 > 0.0f && d2 > 0.0f) {
+        if (d1 < d2) { // left first: push right, continue with left
+          stack[sp * STRIDE] = (int)right;
+          sp++;
+          ref = left;
+        } else {
+          stack[sp * STRIDE] = (int)left;
+          sp++;
+          ref = right;
+        }
+        continue;
+      } else if (d1 > 0.0f) {
+        ref = left;
+        continue;
+      } else if (d2 > 0.0f) {
+        ref = right;
+        continue;
+      }
+    }
+    if (sp == 0) break;
+    sp--;
+    ref = (uint32_t)stack[sp * STRIDE];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Winner reconstruction: the rest of hitTriangle (P5/fsh:172-178, 199-214) and
+// getMaterial (P5/fsh:110-135), evaluated once per ray for the closest hit.
+struct Mat {
+  f3 emissive, baseColor;
+  float subsurface, metallic, specular, specularTint, roughness, anisotropic;
+  float sheen, sheenTint, clearcoat, clearcoatGloss;
+};
+struct Hit {
+  f3 P, N, viewDir;
+  Mat m;
+};
+
+EZD f3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
+
+template <bool P5TRI>
+EZD void shade_point(const DevScene& sc, int32_t tri, float t, f3 S, f3 d, Hit& h) {
+  const float4* g = sc.tri_geom + (size_t)tri * 3;
+  float4 a = g[0], b = g[1], c = g[2];
+  f3 p1 = mk(a.x, a.y, a.z), p2 = mk(b.x, b.y, b.z), p3 = mk(c.x, c.y, c.z);
+  f3 N = mk(a.w, b.w, c.w);
+  bool inside = dot(N, d) > 0.0f;
+  f3 P = S + d * t;
+  const float* r = sc.tri_ref + (size_t)tri * 36;
+  f3 n1 = ld3(r + 9), n2 = ld3(r + 12), n3 = ld3(r + 15);
+  float alpha, beta;
+  if (P5TRI) { // P5/fsh:206-207
+    alpha = (-(P.x - p2.x) * (p3.y - p2.y) + (P.y - p2.y) * (p3.x - p2.x)) /
+            (-(p1.x - p2.x) * (p3.y - p2.y) + (p1.y - p2.y) * (p3.x - p2.x) + 1e-7f);
+    beta = (-(P.x - p3.x) * (p1.y - p3.y) + (P.y - p3.y) * (p1.x - p3.x)) /
+           (-(p2.x - p3.x) * (p1.y - p3.y) + (p2.y - p3.y) * (p1.x - p3.x) + 1e-7f);
+  } else { // P3/fsh:273-274, P4/fsh:196-197
+    alpha = (-(P.x - p2.x) * (p3.y - p2.y) + (P.y - p2.y) * (p3.x - p2.x)) /
+            (-(p1.x - p2.x - 0.00005f) * (p3.y - p2.y + 0.00005f) + (p1.y - p2.y + 0.00005f) * (p3.x - p2.x + 0.00005f));
+    beta = (-(P.x - p3.x) * (p1.y - p3.y) + (P.y - p3.y) * (p1.x - p3.x)) /
+           (-(p2.x - p3.x - 0.00005f) * (p1.y - p3.y + 0.00005f) + (p2.y - p3.y + 0.00005f) * (p1.x - p3.x + 0.00005f));
+  }
+  float gama = 1.0f - alpha - beta;
+  f3 Ns = normalize(n1 * alpha + n2 * beta + n3 * gama);
+  h.P = P;
+  h.N = inside ? -Ns : Ns;
+  h.viewDir = d;
+  h.m.emissive = ld3(r + 18);
+  h.m.baseColor = ld3(r + 21);
+  h.m.subsurface = r[24];
+  h.m.metallic = r[25];
+  h.m.specular = r[26];
+  h.m.specularTint = r[27];
+  h.m.roughness = r[28];
+  h.m.anisotropic = r[29];
+  h.m.sheen = r[30];
+  h.m.sheenTint = r[31];
+  h.m.clearcoat = r[32];
+  h.m.clearcoatGloss = r[33];
+}
+
+// ---------------------------------------------------------------------------
+// textures.  Defined (reference leaves it to the driver): texel-centre
+// sampling, clamp-to-edge, NEAREST = floor(u*W), BILINEAR = GL formula in fp32
+// with x-lerp then y-lerp.  NaN coordinates read texel 0.
+EZD float sane01(float u) {
+  if (!(u == u)) return 0.0f;
+  return ez_clamp(u, 0.0f, 1.0f);
+}
+EZD f3 tex_fetch(const float4* __restrict__ img, int W, int H, int filter, float u, float v) {
+  u = sane01(u);
+  v = sane01(v);
+  if (filter == EZRT_FILTER_NEAREST) {
+    int ix = (int)ez_floor(u * (float)W), iy = (int)ez_floor(v * (float)H);
+    if (ix > W - 1) ix = W - 1;
+    if (iy > H - 1) iy = H - 1;
+    float4 p = img[(size_t)iy * W + ix];
+    return mk(p.x, p.y, p.z);
+  }
+  float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+  float x0 = ez_floor(x), y0 = ez_floor(y);
+  float fx = x - x0, fy = y - y0;
+  int ix0 = (int)x0, iy0 = (int)y0, ix1 = ix0 + 1, iy1 = iy0 + 1;
+  if (ix0 < 0) ix0 = 0;
+  if (iy0 < 0) iy0 = 0;
+  if (ix1 > W - 1) ix1 = W - 1;
+  if (iy1 > H - 1) iy1 = H - 1;
+  float4 p00 = img[(size_t)iy0 * W + ix0], p10 = img[(size_t)iy0 * W + ix1];
+  float4 p01 = img[(size_t)iy1 * W + ix0], p11 = img[(size_t)iy1 * W + ix1];
+  f3 top = mix3(mk(p00.x, p00.y, p00.z), mk(p10.x, p10.y, p10.z), fx);
+  f3 bot = mix3(mk(p01.x, p01.y, p01.z), mk(p11.x, p11.y, p11.z), fx);
+  return mix3(top, bot, fy);
+}
+
+// toSphericalCoord: P5/fsh:684-690
+EZD void to_spherical(f3 v, float& u, float& w) {
+  u = ez_atan2(v.z, v.x);
+  w = ez_asin(v.y);
+  u = u / (2.0f * PI);
+  w = w / PI;
+  u = u + 0.5f;
+  w = w + 0.5f;
+  w = 1.0f - w;
+}
+// hdrColor: P5/fsh:693-697 (P3 clamp: P3/fsh:151-156)
+template <bool FULLCTR>
+EZD f3 hdr_color(const DevScene& sc, f3 L, float env_clamp, Counters& ctr) {
+  if (FULLCTR) ctr.envmap++;
+  if (!sc.hdr) return mk(0, 0, 0);
+  float u, v;
+  to_spherical(normalize(L), u, v);
+  f3 c = tex_fetch(sc.hdr, sc.env_w, sc.env_h, sc.env_filter, u, v);
+  if (env_clamp > 0.0f) c = mk(ez_min(c.x, env_clamp), ez_min(c.y, env_clamp), ez_min(c.z, env_clamp));
+  return c;
+}
+// SampleHdr: P5/fsh:667-679
+template <bool FULLCTR>
+EZD f3 sample_hdr(const DevScene& sc, float xi1, float xi2, Counters& ctr) {
+  if (FULLCTR) ctr.envcache++;
+  f3 c = tex_fetch(sc.cache, sc.env_w, sc.env_h, sc.env_filter, xi1, xi2);
+  float x = c.x, y = 1.0f - c.y;
+  float phi = 2.0f * PI * (x - 0.5f);
+  float theta = PI * (y - 0.5f);
+  float st, ct, sp, cp;
+  ez_sincos(theta, &st, &ct);
+  ez_sincos(phi, &sp, &cp);
+  return mk(ct * cp, st, ct * sp);
+}
+// hdrPdf: P5/fsh:701-712
+template <bool FULLCTR>
+EZD float hdr_pdf(const DevScene& sc, f3 L, Counters& ctr) {
+  if (FULLCTR) ctr.envcache++;
+  float u, v;
+  to_spherical(normalize(L), u, v);
+  float pdf = tex_fetch(sc.cache, sc.env_w, sc.env_h, sc.env_filter, u, v).z;
+  float theta = PI * (0.5f - v);
+  float sin_theta = ez_max(ez_sin(theta), 1e-10f);
+  int res = sc.env_w;
+  float p_convert = (float)(res * res / 2) / (2.0f * PI * PI * sin_theta);
+  return pdf * p_convert;
+}
+
+// ---------------------------------------------------------------------------
+// Disney principled BRDF: P5/fsh:400-549 (isotropic), P4/fsh:375-473 (anisotropic)
+EZD float schlick(float u) {
+  float m = ez_clamp(1.0f - u, 0.0f, 1.0f);
+  float m2 = m * m;
+  return m2 * m2 * m;
+}
+EZD float gtr1(float NdotH, float a) {
+  if (a >= 1.0f) return 1.0f / PI;
+  float a2 = a * a;
+  float t = 1.0f + (a2 - 1.0f) * NdotH * NdotH;
+  return (a2 - 1.0f) / (PI * ez_log(a2) * t);
+}
+EZD float gtr2(float NdotH, float a) {
+  float a2 = a * a;
+  float t = 1.0f + (a2 - 1.0f) * NdotH * NdotH;
+  return a2 / (PI * t * t);
+}
+EZD float gtr2_aniso(float NdotH, float HdotX, float HdotY, float ax, float ay) {
+  return 1.0f / (PI * ax * ay * sqr(sqr(HdotX / ax) + sqr(HdotY / ay) + NdotH * NdotH));
+}
+EZD float smith_ggx(float NdotV, float alphaG) {
+  float a = alphaG * alphaG;
+  float b = NdotV * NdotV;
+  return 1.0f / (NdotV + __builtin_sqrtf(a + b - a * b));
+}
+EZD float smith_ggx_aniso(float NdotV, float VdotX, float VdotY, float ax, float ay) {
+  return 1.0f / (NdotV + __builtin_sqrtf(sqr(VdotX * ax) + sqr(VdotY * ay) + sqr(NdotV)));
+}
+
+template <bool ANISO>
+EZD f3 brdf_evaluate(f3 V, f3 N, f3 L, f3 X, f3 Y, const Mat& m) {
+  float NdotL = dot(N, L), NdotV = dot(N, V);
+  if (NdotL < 0.0f || NdotV < 0.0f) return mk(0, 0, 0);
+  f3 H = normalize(L + V);
+  float NdotH = dot(N, H), LdotH = dot(L, H);
+
+  f3 Cdlin = m.baseColor;
+  float Cdlum = 0.3f * Cdlin.x + 0.6f * Cdlin.y + 0.1f * Cdlin.z;
+  f3 one = mk(1, 1, 1);
+  f3 Ctint = (Cdlum > 0.0f) ? (Cdlin / Cdlum) : one;
+  f3 Cspec = mix3(one, Ctint, m.specularTint) * m.specular;
+  f3 Cspec0 = mix3(Cspec * 0.08f, Cdlin, m.metallic);
+  f3 Csheen = mix3(one, Ctint, m.sheenTint);
+
+  float Fd90 = 0.5f + 2.0f * LdotH * LdotH * m.roughness;
+  float FL = schlick(NdotL), FV = schlick(NdotV);
+  float Fd = ez_mix(1.0f, Fd90, FL) * ez_mix(1.0f, Fd90, FV);
+
+  float Fss90 = LdotH * LdotH * m.roughness;
+  float Fss = ez_mix(1.0f, Fss90, FL) * ez_mix(1.0f, Fss90, FV);
+  float ss = 1.25f * (Fss * (1.0f / (NdotL + NdotV) - 0.5f) + 0.5f);
+
+  float Ds, Gs;
+  float FH = schlick(LdotH);
+  f3 Fs = mix3(Cspec0, one, FH);
+  if (!ANISO) {
+    float alpha = ez_max(0.001f, sqr(m.roughness));
+    Ds = gtr2(NdotH, alpha);
+    Gs = smith_ggx(NdotL, m.roughness);
+    Gs *= smith_ggx(NdotV, m.roughness);
+  } else {
+    float aspect = __builtin_sqrtf(1.0f - m.anisotropic * 0.9f);
+    float ax = ez_max(0.001f, sqr(m.roughness) / aspect);
+    float ay = ez_max(0.001f, sqr(m.roughness) * aspect);
+    Ds = gtr2_aniso(NdotH, dot(H, X), dot(H, Y), ax, ay);
+    Gs = smith_ggx_aniso(NdotL, dot(L, X), dot(L, Y), ax, ay);
+    Gs *= smith_ggx_aniso(NdotV, dot(V, X), dot(V, Y), ax, ay);
+  }
+  float Dr = gtr1(NdotH, ez_mix(0.1f, 0.001f, m.clearcoatGloss));
+  float Fr = ez_mix(0.04f, 1.0f, FH);
+  float Gr = smith_ggx(NdotL, 0.25f) * smith_ggx(NdotV, 0.25f);
+
+  f3 Fsheen = Csheen * (FH * m.sheen);
+  f3 diffuse = Cdlin * ((1.0f / PI) * ez_mix(Fd, ss, m.subsurface)) + Fsheen;
+  f3 specular = (Fs * Gs) * Ds;
+  float cc = 0.25f * Gr * Fr * Dr * m.clearcoat;
+  return (diffuse * (1.0f - m.metallic) + specular) + mk(cc, cc, cc);
+}
+
+// getTangent: P5/fsh:553-558
+EZD void get_tangent(f3 N, f3& tangent, f3& bitangent) {
+  f3 helper = mk(1, 0, 0);
+  if (ez_abs(N.x) > 0.999f) helper = mk(0, 0, 1);
+  bitangent = normalize(cross(N, helper));
+  tangent = normalize(cross(N, bitangent));
+}
+// toNormalHemisphere: P5/fsh:561-567
+EZD f3 to_normal_hemisphere(f3 v, f3 N) {
+  f3 helper = mk(1, 0, 0);
+  if (ez_abs(N.x) > 0.999f) helper = mk(0, 0, 1);
+  f3 tangent = normalize(cross(N, helper));
+  f3 bitangent = normalize(cross(N, tangent));
+  return (tangent * v.x + bitangent * v.y) + N * v.z;
+}
+// SampleHemisphere: P5/fsh:570-576
+EZD f3 sample_hemisphere(float xi1, float xi2) {
+  float z = xi1;
+  float r = ez_max(0.0f, __builtin_sqrtf(1.0f - z * z));
+  float phi = 2.0f * PI * xi2;
+  float s, c;
+  ez_sincos(phi, &s, &c);
+  return mk(r * c, r * s, z);
+}
+// SampleCosineHemisphere: P5/fsh:579-590
+EZD f3 sample_cosine_hemisphere(float xi1, float xi2, f3 N) {
+  float r = __builtin_sqrtf(xi1);
+  float theta = xi2 * 2.0f * PI;
+  float s, c;
+  ez_sincos(theta, &s, &c);
+  float x = r * c, y = r * s;
+  float z = __builtin_sqrtf(1.0f - x * x - y * y);
+  return to_normal_hemisphere(mk(x, y, z), N);
+}
+// SampleGTR2 / SampleGTR1: P5/fsh:593-630
+EZD f3 sample_gtr(float xi1, f3 V, f3 N, float cos_theta_h) {
+  float phi_h = 2.0f * PI * xi1;
+  float sin_phi_h, cos_phi_h;
+  ez_sincos(phi_h, &sin_phi_h, &cos_phi_h);
+  float sin_theta_h = __builtin_sqrtf(ez_max(0.0f, 1.0f - cos_theta_h * cos_theta_h));
+  f3 H = mk(sin_theta_h * cos_phi_h, sin_theta_h * sin_phi_h, cos_theta_h);
+  H = to_normal_hemisphere(H, N);
+  return reflect(-V, H);
+}
+// SampleBRDF: P5/fsh:633-664
+EZD f3 sample_brdf(float xi1, float xi2, float xi3, f3 V, f3 N, const Mat& m) {
+  float alpha_GTR1 = ez_mix(0.1f, 0.001f, m.clearcoatGloss);
+  float alpha_GTR2 = ez_max(0.001f, sqr(m.roughness));
+  float r_diffuse = 1.0f - m.metallic;
+  float r_specular = 1.0f;
+  float r_clearcoat = 0.25f * m.clearcoat;
+  float r_sum = r_diffuse + r_specular + r_clearcoat;
+  float p_diffuse = r_diffuse / r_sum;
+  float p_specular = r_specular / r_sum;
+  float rd = xi3;
+  if (rd <= p_diffuse) return sample_cosine_hemisphere(xi1, xi2, N);
+  if (p_diffuse < rd && rd <= p_diffuse + p_specular) {
+    float c = __builtin_sqrtf((1.0f - xi2) / (1.0f + (alpha_GTR2 * alpha_GTR2 - 1.0f) * xi2));
+    return sample_gtr(xi1, V, N, c);
+  }
+  if (p_diffuse + p_specular < rd) {
+    float c = __builtin_sqrtf((1.0f - ez_pow(alpha_GTR1 * alpha_GTR1, 1.0f - xi2)) / (1.0f - alpha_GTR1 * alpha_GTR1));
+    return sample_gtr(xi1, V, N, c);
+  }
+  return mk(0, 1, 0);
+}
+// BRDF_Pdf: P5/fsh:715-752
+EZD float brdf_pdf(f3 V, f3 N, f3 L, const Mat& m) {
+  float NdotL = dot(N, L), NdotV = dot(N, V);
+  if (NdotL < 0.0f || NdotV < 0.0f) return 0.0f;
+  f3 H = normalize(L + V);
+  float NdotH = dot(N, H), LdotH = dot(L, H);
+  float alpha = ez_max(0.001f, sqr(m.roughness));
+  float Ds = gtr2(NdotH, alpha);
+  float Dr = gtr1(NdotH, ez_mix(0.1f, 0.001f, m.clearcoatGloss));
+  float pdf_diffuse = NdotL / PI;
+  float pdf_specular = Ds * NdotH / (4.0f * LdotH);
+  float pdf_clearcoat = Dr * NdotH / (4.0f * LdotH);
+  float r_diffuse = 1.0f - m.metallic;
+  float r_specular = 1.0f;
+  float r_clearcoat = 0.25f * m.clearcoat;
+  float r_sum = r_diffuse + r_specular + r_clearcoat;
+  float p_diffuse = r_diffuse / r_sum;
+  float p_specular = r_specular / r_sum;
+  float p_clearcoat = r_clearcoat / r_sum;
+  float pdf = p_diffuse * pdf_diffuse + p_specular * pdf_specular + p_clearcoat * pdf_clearcoat;
+  return ez_max(1e-10f, pdf);
+}
+EZD float mis_mix_weight(float a, float b) { // P5/fsh:754-757
+  float t = a * a;
+  return t / (b * b + t);
+}
+
+} // namespace ezd

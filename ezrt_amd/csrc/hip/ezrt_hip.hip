@@ -1,0 +1,577 @@
+// ezrt_hip.hip -- libezrt_hip.so: the C ABI of include/ezrt.h implemented on
+// hand-written gfx950 kernels (ezrt_kernels.h).  Host code here only validates,
+// re-lays the scene out for the GPU, and launches; there is no CPU compute path.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ezrt.h"
+#include "ezrt_kernels.h"
+
+using namespace ezd;
+
+namespace {
+
+thread_local char g_err[512];
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(expr)                                                                           \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) return fail(EZRT_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  hipError_t ensure(size_t count) {
+    if (count <= n && p) return hipSuccess;
+    release();
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+};
+
+constexpr int MAX_TRACE_EVENTS = 64;
+
+} // namespace
+
+struct EzrtScene {
+  int n_tri = 0, n_nodes = 0;
+  DevBuf<float4> tri_geom;
+  DevBuf<float> tri_ref;
+  DevBuf<float4> inner;
+  DevBuf<float4> hdr, cache;
+  uint32_t root_ref = 0;
+  int env_w = 0, env_h = 0, env_filter = 0;
+  bool has_cache = false;
+  int instr = 0;
+  int depth = 0;
+  int64_t stats[6] = {0, 0, 0, 0, 0, 0};
+  DevBuf<unsigned long long> counters;
+  // render scratch
+  DevBuf<int2> blocks;
+  std::vector<int2> blocks_host;
+  EzrtRenderParams blocks_for; // params the block list was built for
+  bool blocks_valid = false;
+  DevBuf<float4> samples;
+  DevBuf<float4> accum_tmp;
+  // timing
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  hipEvent_t ev_trace[MAX_TRACE_EVENTS][2];
+  int n_trace_events = 0, n_trace_launches = 0;
+  bool timed = false;
+
+  DevScene dev() const {
+    DevScene d;
+    d.tri_geom = tri_geom.p;
+    d.tri_ref = tri_ref.p;
+    d.inner = inner.p;
+    d.root_ref = root_ref;
+    d.n_tri = n_tri;
+    d.hdr = hdr.p;
+    d.cache = has_cache ? cache.p : nullptr;
+    d.env_w = env_w;
+    d.env_h = env_h;
+    d.env_filter = env_filter;
+    return d;
+  }
+};
+
+namespace {
+
+struct HostNode {
+  int left, right, n, index;
+  float AA[3], BB[3];
+};
+HostNode decode_node(const float* nodes, int i) {
+  const float* p = nodes + (size_t)i * EZRT_NODE_FLOATS;
+  HostNode h;
+  h.left = (int)p[0]; // ivec3(texelFetch) truncation, P5/fsh:143-148
+  h.right = (int)p[1];
+  h.n = (int)p[3];
+  h.index = (int)p[4];
+  for (int k = 0; k < 3; k++) {
+    h.AA[k] = p[6 + k];
+    h.BB[k] = p[9 + k];
+  }
+  return h;
+}
+
+int validate_params(const EzrtScene* s, const EzrtRenderParams* p) {
+  if (!p) return fail(EZRT_ERR_INVALID, "params is NULL");
+  if (p->width <= 0 || p->height <= 0) return fail(EZRT_ERR_INVALID, "width/height must be positive");
+  if (p->x0 < 0 || p->y0 < 0 || p->x1 > p->width || p->y1 > p->height || p->x0 > p->x1 || p->y0 > p->y1)
+    return fail(EZRT_ERR_INVALID, "pixel rect outside the image");
+  if (p->max_bounce < 0 || p->max_bounce > 64) return fail(EZRT_ERR_INVALID, "max_bounce out of range [0,64]");
+  if (p->integrator != 3 && p->integrator != 4 && p->integrator != 50 && p->integrator != 51)
+    return fail(EZRT_ERR_INVALID, "unknown integrator");
+  if (p->shard_count < 0 || p->shard_index < 0 || (p->shard_count > 0 && p->shard_index >= p->shard_count))
+    return fail(EZRT_ERR_INVALID, "bad shard index/count");
+  if (p->tile_w < 0 || p->tile_h < 0) return fail(EZRT_ERR_INVALID, "bad tile size");
+  if (p->integrator == EZRT_INTEGRATOR_P5_MIS && !s->has_cache)
+    return fail(EZRT_ERR_INVALID, "integrator 51 needs the env cache (ezrt_scene_set_env)");
+  return 0;
+}
+
+bool same_blocks(const EzrtRenderParams& a, const EzrtRenderParams& b) {
+  return a.width == b.width && a.height == b.height && a.x0 == b.x0 && a.y0 == b.y0 && a.x1 == b.x1 && a.y1 == b.y1 &&
+         a.tile_w == b.tile_w && a.tile_h == b.tile_h && a.shard_index == b.shard_index && a.shard_count == b.shard_count;
+}
+bool owned_host(const EzrtRenderParams& p, int x, int y) {
+  if (x < p.x0 || x >= p.x1 || y < p.y0 || y >= p.y1) return false;
+  if (p.shard_count <= 1) return true;
+  int tw = p.tile_w > 0 ? p.tile_w : 32, th = p.tile_h > 0 ? p.tile_h : 32;
+  int tiles_x = (p.width + tw - 1) / tw;
+  int tile = (y / th) * tiles_x + (x / tw);
+  return tile % p.shard_count == p.shard_index;
+}
+
+// list of 16x16 pixel blocks holding at least one owned pixel
+int build_blocks(EzrtScene* s, const EzrtRenderParams& p, hipStream_t st) {
+  if (s->blocks_valid && same_blocks(s->blocks_for, p)) return 0;
+  std::vector<int2>& v = s->blocks_host;
+  v.clear();
+  for (int by = (p.y0 / 16) * 16; by < p.y1; by += 16)
+    for (int bx = (p.x0 / 16) * 16; bx < p.x1; bx += 16) {
+      bool any = false;
+      for (int y = by; y < by + 16 && !any; y++)
+        for (int x = bx; x < bx + 16 && !any; x++) any = owned_host(p, x, y);
+      if (any) v.push_back(make_int2(bx, by));
+    }
+  if (!v.empty()) {
+    HIP_TRY(s->blocks.ensure(v.size()));
+    HIP_TRY(hipMemcpyAsync(s->blocks.p, v.data(), v.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st)); // v may be rebuilt by the next call
+  }
+  s->blocks_for = p;
+  s->blocks_valid = true;
+  return 0;
+}
+
+template <int INTEG>
+void launch_trace_i(const TraceArgs& a, int mode, dim3 grid, size_t lds, hipStream_t st) {
+  if (mode == 2) hipLaunchKernelGGL((trace_kernel<INTEG, false, true>), grid, dim3(BLOCK), lds, st, a);
+  else if (mode == 1) hipLaunchKernelGGL((trace_kernel<INTEG, true, false>), grid, dim3(BLOCK), lds, st, a);
+  else hipLaunchKernelGGL((trace_kernel<INTEG, false, false>), grid, dim3(BLOCK), lds, st, a);
+}
+// mode: 0 timed, 1 full counters, 2 path log
+void launch_trace(const TraceArgs& a, int mode, dim3 grid, size_t lds, hipStream_t st) {
+  switch (a.p.integrator) {
+    case EZRT_INTEGRATOR_P3_DIFFUSE: launch_trace_i<EZRT_INTEGRATOR_P3_DIFFUSE>(a, mode, grid, lds, st); break;
+    case EZRT_INTEGRATOR_P4_DISNEY: launch_trace_i<EZRT_INTEGRATOR_P4_DISNEY>(a, mode, grid, lds, st); break;
+    case EZRT_INTEGRATOR_P5_SOBOL: launch_trace_i<EZRT_INTEGRATOR_P5_SOBOL>(a, mode, grid, lds, st); break;
+    default: launch_trace_i<EZRT_INTEGRATOR_P5_MIS>(a, mode, grid, lds, st); break;
+  }
+}
+
+int ensure_events(EzrtScene* s) {
+  if (s->ev_begin) return 0;
+  HIP_TRY(hipEventCreate(&s->ev_begin));
+  HIP_TRY(hipEventCreate(&s->ev_end));
+  for (int i = 0; i < MAX_TRACE_EVENTS; i++) {
+    HIP_TRY(hipEventCreate(&s->ev_trace[i][0]));
+    HIP_TRY(hipEventCreate(&s->ev_trace[i][1]));
+  }
+  return 0;
+}
+
+size_t stack_lds_bytes(const EzrtScene* s) {
+  int entries = s->depth > 1 ? s->depth : 1; // pending far children <= depth - 1
+  return (size_t)entries * BLOCK * sizeof(int);
+}
+
+} // namespace
+
+extern "C" {
+
+const char* ezrt_last_error(void) { return g_err; }
+const char* ezrt_backend(void) { return "hip:gfx950"; }
+
+int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nodes, EzrtScene** out) {
+  if (!out) return fail(EZRT_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (!tri || !nodes || n_tri <= 0 || n_nodes <= 0) return fail(EZRT_ERR_INVALID, "empty scene arrays");
+  if (n_tri >= (1 << 24) || n_nodes >= (1 << 24))
+    return fail(EZRT_ERR_UNSUPPORTED, "counts >= 2^24 are not exact in the float encoding");
+  if (n_nodes < 2) return fail(EZRT_ERR_INVALID, "need at least the dummy node 0 and the root node 1");
+
+  // ---- validate + measure the tree (pre-order ids: child > parent)
+  std::vector<int> depth((size_t)n_nodes, 0), inner_id((size_t)n_nodes, -1);
+  int64_t leaves = 0, maxleaf = 0;
+  int n_inner = 0;
+  for (int i = 1; i < n_nodes; i++) {
+    HostNode h = decode_node(nodes, i);
+    if (h.n > 0) {
+      if (h.index < 0 || (int64_t)h.index + h.n > n_tri)
+        return fail(EZRT_ERR_INVALID, "leaf %d: triangle range outside the triangle array", i);
+      leaves++;
+      if (h.n > maxleaf) maxleaf = h.n;
+    } else {
+      if (h.left <= i || h.right <= i || h.left >= n_nodes || h.right >= n_nodes)
+        return fail(EZRT_ERR_INVALID, "inner node %d: children must satisfy parent < child < nNodes", i);
+      inner_id[(size_t)i] = n_inner++;
+    }
+  }
+  int maxd = 1;
+  depth[1] = 1;
+  for (int i = 1; i < n_nodes; i++) {
+    if (depth[(size_t)i] == 0) continue;
+    HostNode h = decode_node(nodes, i);
+    if (h.n <= 0) {
+      depth[(size_t)h.left] = depth[(size_t)i] + 1;
+      depth[(size_t)h.right] = depth[(size_t)i] + 1;
+    }
+    if (depth[(size_t)i] > maxd) maxd = depth[(size_t)i];
+  }
+  if (maxd + 1 > 256) return fail(EZRT_ERR_UNSUPPORTED, "tree deeper than the reference's 256-entry stack");
+  if (maxleaf > 128) return fail(EZRT_ERR_UNSUPPORTED, "leaf with %lld triangles: this build packs leaf size in 7 bits (<= 128)", (long long)maxleaf);
+  if ((size_t)maxd * BLOCK * sizeof(int) > 150 * 1024)
+    return fail(EZRT_ERR_UNSUPPORTED, "tree depth %d needs more LDS stack than one CU has", maxd);
+
+  // ---- device layout
+  auto ref_of = [&](int node) -> uint32_t {
+    HostNode h = decode_node(nodes, node);
+    if (h.n > 0) return LEAF_BIT | ((uint32_t)(h.n - 1) << 24) | (uint32_t)h.index;
+    return (uint32_t)inner_id[(size_t)node];
+  };
+  std::vector<float4> inner((size_t)(n_inner > 0 ? n_inner : 1) * 4);
+  for (int i = 1; i < n_nodes; i++) {
+    if (inner_id[(size_t)i] < 0) continue;
+    HostNode h = decode_node(nodes, i);
+    HostNode l = decode_node(nodes, h.left), r = decode_node(nodes, h.right);
+    float4* q = &inner[(size_t)inner_id[(size_t)i] * 4];
+    q[0] = make_float4(l.AA[0], l.AA[1], l.AA[2], l.BB[0]);
+    q[1] = make_float4(l.BB[1], l.BB[2], r.AA[0], r.AA[1]);
+    q[2] = make_float4(r.AA[2], r.BB[0], r.BB[1], r.BB[2]);
+    uint32_t lr = ref_of(h.left), rr = ref_of(h.right);
+    float lf, rf;
+    memcpy(&lf, &lr, 4);
+    memcpy(&rf, &rr, 4);
+    q[3] = make_float4(lf, rf, 0.0f, 0.0f);
+  }
+  std::vector<float4> geom((size_t)n_tri * 3);
+  for (int i = 0; i < n_tri; i++) {
+    const float* t = tri + (size_t)i * EZRT_TRI_FLOATS;
+    // N = normalize(cross(p2 - p1, p3 - p1)), P5/fsh:172 -- same fp32 ops, contraction off
+    float e1x = t[3] - t[0], e1y = t[4] - t[1], e1z = t[5] - t[2];
+    float e2x = t[6] - t[0], e2y = t[7] - t[1], e2z = t[8] - t[2];
+    float cx = e1y * e2z - e1z * e2y, cy = e1z * e2x - e1x * e2z, cz = e1x * e2y - e1y * e2x;
+    float inv = 1.0f / __builtin_sqrtf(cx * cx + cy * cy + cz * cz);
+    geom[(size_t)i * 3 + 0] = make_float4(t[0], t[1], t[2], cx * inv);
+    geom[(size_t)i * 3 + 1] = make_float4(t[3], t[4], t[5], cy * inv);
+    geom[(size_t)i * 3 + 2] = make_float4(t[6], t[7], t[8], cz * inv);
+  }
+
+  EzrtScene* s = new (std::nothrow) EzrtScene();
+  if (!s) return fail(EZRT_ERR_NOMEM, "out of memory");
+  s->n_tri = n_tri;
+  s->n_nodes = n_nodes;
+  s->depth = maxd;
+  s->root_ref = ref_of(1);
+#define SC_TRY(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      delete s;                                                                                   \
+      return fail(EZRT_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));                \
+    }                                                                                             \
+  } while (0)
+  SC_TRY(s->tri_geom.ensure(geom.size()));
+  SC_TRY(s->tri_ref.ensure((size_t)n_tri * EZRT_TRI_FLOATS));
+  SC_TRY(s->inner.ensure(inner.size()));
+  SC_TRY(s->counters.ensure(EZRT_CTR_COUNT));
+  SC_TRY(hipMemcpy(s->tri_geom.p, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice));
+  SC_TRY(hipMemcpy(s->tri_ref.p, tri, (size_t)n_tri * EZRT_TRI_FLOATS * sizeof(float), hipMemcpyHostToDevice));
+  SC_TRY(hipMemcpy(s->inner.p, inner.data(), inner.size() * sizeof(float4), hipMemcpyHostToDevice));
+  SC_TRY(hipMemset(s->counters.p, 0, EZRT_CTR_COUNT * sizeof(unsigned long long)));
+#undef SC_TRY
+  s->stats[0] = n_tri;
+  s->stats[1] = n_nodes;
+  s->stats[2] = maxd;
+  s->stats[3] = leaves;
+  s->stats[4] = maxleaf;
+  s->stats[5] = (int64_t)(geom.size() * sizeof(float4) + (size_t)n_tri * 144 + inner.size() * sizeof(float4));
+  *out = s;
+  return 0;
+}
+
+void ezrt_scene_destroy(EzrtScene* s) {
+  if (!s) return;
+  if (s->ev_begin) {
+    (void)hipEventDestroy(s->ev_begin);
+    (void)hipEventDestroy(s->ev_end);
+    for (int i = 0; i < MAX_TRACE_EVENTS; i++) {
+      (void)hipEventDestroy(s->ev_trace[i][0]);
+      (void)hipEventDestroy(s->ev_trace[i][1]);
+    }
+  }
+  delete s;
+}
+
+int ezrt_scene_set_env(EzrtScene* s, const float* hdr, const float* cache, int w, int h, int filter) {
+  if (!s || !hdr || w <= 0 || h <= 0) return fail(EZRT_ERR_INVALID, "bad env arguments");
+  if (filter != EZRT_FILTER_NEAREST && filter != EZRT_FILTER_BILINEAR) return fail(EZRT_ERR_INVALID, "bad filter");
+  if ((int64_t)w * w / 2 >= ((int64_t)1 << 31)) return fail(EZRT_ERR_UNSUPPORTED, "hdrResolution^2/2 overflows int");
+  size_t n = (size_t)w * h;
+  std::vector<float4> tmp(n);
+  for (size_t i = 0; i < n; i++) tmp[i] = make_float4(hdr[i * 3], hdr[i * 3 + 1], hdr[i * 3 + 2], 0.0f);
+  HIP_TRY(s->hdr.ensure(n));
+  HIP_TRY(hipMemcpy(s->hdr.p, tmp.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+  s->has_cache = false;
+  if (cache) {
+    for (size_t i = 0; i < n; i++) tmp[i] = make_float4(cache[i * 3], cache[i * 3 + 1], cache[i * 3 + 2], 0.0f);
+    HIP_TRY(s->cache.ensure(n));
+    HIP_TRY(hipMemcpy(s->cache.p, tmp.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+    s->has_cache = true;
+  }
+  s->env_w = w;
+  s->env_h = h;
+  s->env_filter = filter;
+  return 0;
+}
+
+int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev, void* stream) {
+  if (!s || !accum_dev) return fail(EZRT_ERR_INVALID, "scene/accum is NULL");
+  int rc = validate_params(s, p);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  rc = ensure_events(s);
+  if (rc) return rc;
+  rc = build_blocks(s, *p, st);
+  if (rc) return rc;
+  s->timed = false;
+  s->n_trace_events = 0;
+  s->n_trace_launches = 0;
+  const int nb = (int)s->blocks_host.size();
+  HIP_TRY(hipEventRecord(s->ev_begin, st));
+  if (nb > 0 && p->spp > 0) {
+    // frames per launch: bound the sample buffer to ~512 MiB
+    const size_t per_frame = (size_t)nb * BLOCK;
+    size_t chunk = (size_t)(32u << 20) / per_frame;
+    if (chunk < 1) chunk = 1;
+    if (chunk > p->spp) chunk = p->spp;
+    HIP_TRY(s->samples.ensure(per_frame * chunk));
+    const size_t lds = stack_lds_bytes(s);
+    for (uint32_t done = 0; done < p->spp;) {
+      uint32_t nf = (uint32_t)((p->spp - done < chunk) ? (p->spp - done) : chunk);
+      TraceArgs a;
+      a.sc = s->dev();
+      a.p = *p;
+      a.blocks = s->blocks.p;
+      a.n_blocks = nb;
+      a.frame_first = p->frame0 + done;
+      a.samples = s->samples.p;
+      a.counters = s->counters.p;
+      a.log_tri = nullptr;
+      a.log_t = nullptr;
+      a.log_colour = nullptr;
+      a.stack_entries = s->depth;
+      int e = s->n_trace_events;
+      if (e < MAX_TRACE_EVENTS) HIP_TRY(hipEventRecord(s->ev_trace[e][0], st));
+      launch_trace(a, s->instr > 0 ? 1 : 0, dim3((unsigned)((size_t)nb * nf)), lds, st);
+      if (e < MAX_TRACE_EVENTS) {
+        HIP_TRY(hipEventRecord(s->ev_trace[e][1], st));
+        s->n_trace_events++;
+      }
+      s->n_trace_launches++;
+      AccumArgs b;
+      b.p = *p;
+      b.blocks = s->blocks.p;
+      b.n_blocks = nb;
+      b.frame_first = p->frame0 + done;
+      b.n_frames = nf;
+      b.samples = s->samples.p;
+      b.accum = reinterpret_cast<float4*>(accum_dev);
+      hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, st, b);
+      done += nf;
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(s->ev_end, st));
+  s->timed = true;
+  return 0;
+}
+
+int ezrt_render(EzrtScene* s, const EzrtRenderParams* p, float* accum) {
+  if (!s || !accum) return fail(EZRT_ERR_INVALID, "scene/accum is NULL");
+  int rc = validate_params(s, p);
+  if (rc) return rc;
+  size_t n = (size_t)p->width * p->height;
+  HIP_TRY(s->accum_tmp.ensure(n));
+  HIP_TRY(hipMemcpy(s->accum_tmp.p, accum, n * sizeof(float4), hipMemcpyHostToDevice));
+  rc = ezrt_render_device(s, p, reinterpret_cast<float*>(s->accum_tmp.p), nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(accum, s->accum_tmp.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int ezrt_render_paths(EzrtScene* s, const EzrtRenderParams* p, int32_t* tri_id, float* t_hit, float* colour) {
+  if (!s || !tri_id || !t_hit) return fail(EZRT_ERR_INVALID, "NULL argument");
+  int rc = validate_params(s, p);
+  if (rc) return rc;
+  rc = build_blocks(s, *p, nullptr);
+  if (rc) return rc;
+  const int nb = (int)s->blocks_host.size();
+  const size_t npix = (size_t)p->width * p->height;
+  const int slots = 1 + 2 * p->max_bounce;
+  DevBuf<int32_t> dtri;
+  DevBuf<float> dt, dcol;
+  HIP_TRY(dtri.ensure(npix * slots));
+  HIP_TRY(dt.ensure(npix * slots));
+  HIP_TRY(dcol.ensure(npix * 3));
+  HIP_TRY(hipMemcpy(dtri.p, tri_id, npix * slots * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dt.p, t_hit, npix * slots * sizeof(float), hipMemcpyHostToDevice));
+  if (colour) HIP_TRY(hipMemcpy(dcol.p, colour, npix * 3 * sizeof(float), hipMemcpyHostToDevice));
+  if (nb > 0) {
+    TraceArgs a;
+    a.sc = s->dev();
+    a.p = *p;
+    a.blocks = s->blocks.p;
+    a.n_blocks = nb;
+    a.frame_first = p->frame0;
+    a.samples = nullptr;
+    a.counters = s->counters.p;
+    a.log_tri = dtri.p;
+    a.log_t = dt.p;
+    a.log_colour = dcol.p;
+    a.stack_entries = s->depth;
+    launch_trace(a, 2, dim3((unsigned)nb), stack_lds_bytes(s), nullptr);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(tri_id, dtri.p, npix * slots * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(t_hit, dt.p, npix * slots * sizeof(float), hipMemcpyDeviceToHost));
+  if (colour) HIP_TRY(hipMemcpy(colour, dcol.p, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int ezrt_query_hits(EzrtScene* s, const float* rays, int n_rays, int32_t* tri_id, float* t_hit) {
+  if (!s || !rays || !tri_id || !t_hit || n_rays < 0) return fail(EZRT_ERR_INVALID, "NULL argument");
+  if (n_rays == 0) return 0;
+  DevBuf<float> dr, dt;
+  DevBuf<int32_t> dtri;
+  HIP_TRY(dr.ensure((size_t)n_rays * 6));
+  HIP_TRY(dt.ensure((size_t)n_rays));
+  HIP_TRY(dtri.ensure((size_t)n_rays));
+  HIP_TRY(hipMemcpy(dr.p, rays, (size_t)n_rays * 6 * sizeof(float), hipMemcpyHostToDevice));
+  QueryArgs a;
+  a.sc = s->dev();
+  a.rays = dr.p;
+  a.n = n_rays;
+  a.tri = dtri.p;
+  a.t = dt.p;
+  a.counters = s->counters.p;
+  dim3 grid((unsigned)((n_rays + BLOCK - 1) / BLOCK));
+  if (s->instr > 0) hipLaunchKernelGGL(query_kernel<true>, grid, dim3(BLOCK), stack_lds_bytes(s), nullptr, a);
+  else hipLaunchKernelGGL(query_kernel<false>, grid, dim3(BLOCK), stack_lds_bytes(s), nullptr, a);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(tri_id, dtri.p, (size_t)n_rays * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(t_hit, dt.p, (size_t)n_rays * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int ezrt_tonemap(const float* rgba, int n_pixels, uint8_t* rgb8) {
+  if (!rgba || !rgb8 || n_pixels < 0) return fail(EZRT_ERR_INVALID, "NULL argument");
+  if (n_pixels == 0) return 0;
+  DevBuf<float4> din;
+  DevBuf<uint8_t> dout;
+  HIP_TRY(din.ensure((size_t)n_pixels));
+  HIP_TRY(dout.ensure((size_t)n_pixels * 3));
+  HIP_TRY(hipMemcpy(din.p, rgba, (size_t)n_pixels * sizeof(float4), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(tonemap_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, nullptr, din.p, n_pixels,
+                     dout.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(rgb8, dout.p, (size_t)n_pixels * 3, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int ezrt_sobol(uint32_t index0, int n, int n_dims, float* out) {
+  if (!out || n < 0 || n_dims < 1 || n_dims > 8) return fail(EZRT_ERR_INVALID, "bad sobol arguments");
+  if (n == 0) return 0;
+  DevBuf<float> d;
+  size_t cnt = (size_t)n * n_dims;
+  HIP_TRY(d.ensure(cnt));
+  hipLaunchKernelGGL(sobol_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, nullptr, index0, n, n_dims, d.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, d.p, cnt * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int ezrt_set_instrumentation(EzrtScene* s, int level) {
+  if (!s || level < 0 || level > 1) return fail(EZRT_ERR_INVALID, "bad instrumentation level");
+  s->instr = level;
+  return 0;
+}
+int ezrt_counters(EzrtScene* s, uint64_t out[EZRT_CTR_COUNT]) {
+  if (!s || !out) return fail(EZRT_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, s->counters.p, EZRT_CTR_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return 0;
+}
+int ezrt_counters_reset(EzrtScene* s) {
+  if (!s) return fail(EZRT_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemset(s->counters.p, 0, EZRT_CTR_COUNT * sizeof(unsigned long long)));
+  return 0;
+}
+int ezrt_last_render_ms(EzrtScene* s, float* total_ms, float* trace_kernel_ms, int* n_trace_launches) {
+  if (!s) return fail(EZRT_ERR_INVALID, "NULL argument");
+  if (!s->timed) return fail(EZRT_ERR_INVALID, "no render call to time yet");
+  HIP_TRY(hipEventSynchronize(s->ev_end));
+  float tot = 0.0f, tr = 0.0f;
+  HIP_TRY(hipEventElapsedTime(&tot, s->ev_begin, s->ev_end));
+  for (int i = 0; i < s->n_trace_events; i++) {
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev_trace[i][0], s->ev_trace[i][1]));
+    tr += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (trace_kernel_ms) *trace_kernel_ms = tr;
+  if (n_trace_launches) *n_trace_launches = s->n_trace_launches;
+  return 0;
+}
+int ezrt_scene_stats(EzrtScene* s, int64_t out[6]) {
+  if (!s || !out) return fail(EZRT_ERR_INVALID, "NULL argument");
+  memcpy(out, s->stats, sizeof s->stats);
+  return 0;
+}
+
+int ezrt_debug_math(int op, const float* a, const float* b, int n, float* out) {
+  if (!a || !out || n < 0 || op < 0 || op > 9) return fail(EZRT_ERR_INVALID, "bad argument");
+  if (n == 0) return 0;
+  DevBuf<float> da, db, dout;
+  HIP_TRY(da.ensure((size_t)n));
+  HIP_TRY(db.ensure((size_t)n));
+  HIP_TRY(dout.ensure((size_t)n));
+  HIP_TRY(hipMemcpy(da.p, a, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  if (b) HIP_TRY(hipMemcpy(db.p, b, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  else HIP_TRY(hipMemset(db.p, 0, (size_t)n * sizeof(float)));
+  hipLaunchKernelGGL(math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, op, da.p, db.p, n, dout.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,357 @@
+// ezrt_kernels.h -- the gfx950 kernels of the trace path.
+//
+//   trace_kernel<INTEG, FULLCTR, PATHLOG>   one thread = one pixel-sample
+//       (ray-gen + hitBVH x (1 + k*bounces) + Disney BRDF + env lookups);
+//       a 256-thread workgroup owns a 16x16 pixel block of one frame, each of
+//       its four wavefronts an 8x8 sub-tile, so the 64 primary rays of a wave
+//       are coherent.  Sample radiance goes to a frame-major sample buffer.
+//   accumulate_kernel    the reference's running mean mix(last, c, 1/(k+1))
+//       (P5/fsh:943-944) applied in frame order, one thread per pixel.
+//   sobol_kernel / tonemap_kernel / query_kernel / math_kernel  small entry
+//       points of the C ABI (KATs, pass3, probe rays, det-math audit).
+//
+// Grid shape: pixel-samples are independent, so the whole chunk of frames is
+// one launch of n_blocks * n_frames workgroups (>> 256 CUs); the hardware
+// dispatcher load-balances the wildly uneven per-pixel cost (sky pixel = 1 ray,
+// bunny pixel = 5).  Block b lands on XCD b % 8 and blockIdx = frame * n_blocks
+// + block, so with n_blocks % 8 == 0 one image block stays on one XCD's L2 for
+// every frame of the chunk.
+#pragma once
+#include "ezrt_device.h"
+
+namespace ezd {
+
+constexpr int BLOCK = 256;
+
+__constant__ uint32_t c_sobol_v[8 * 32] = {
+#include "ezrt_sobol_v.inc"
+};
+
+// sobol(d, i): P5/fsh:361-369
+EZD float sobol(uint32_t d, uint32_t i) {
+  uint32_t result = 0, offset = d * 32u;
+  for (uint32_t j = 0; i != 0; i >>= 1, j++)
+    if (i & 1u) result ^= c_sobol_v[j + offset];
+  return (float)result * (1.0f / (float)0xFFFFFFFFu);
+}
+EZD uint32_t gray_code(uint32_t i) { return i ^ (i >> 1); }
+
+struct TraceArgs {
+  DevScene sc;
+  EzrtRenderParams p;
+  const int2* blocks;   // origin (x, y) of each 16x16 pixel block to render
+  int32_t n_blocks;
+  uint32_t frame_first; // first frame of this launch
+  float4* samples;      // [n_frames][n_blocks * 256]
+  unsigned long long* counters; // EZRT_CTR_COUNT
+  int32_t* log_tri;     // PATHLOG: [H][W][slots]
+  float* log_t;
+  float* log_colour;    // PATHLOG: [H][W][3]
+  int32_t stack_entries;
+};
+
+EZD bool pixel_owned(const EzrtRenderParams& p, int x, int y) {
+  if (x < p.x0 || x >= p.x1 || y < p.y0 || y >= p.y1) return false;
+  if (p.shard_count <= 1) return true;
+  int tw = p.tile_w > 0 ? p.tile_w : 32, th = p.tile_h > 0 ? p.tile_h : 32;
+  int tiles_x = (p.width + tw - 1) / tw;
+  int tile = (y / th) * tiles_x + (x / tw);
+  return tile % p.shard_count == p.shard_index;
+}
+
+EZD unsigned long long wave_sum(uint32_t v) {
+  unsigned long long s = v;
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  return s;
+}
+
+template <bool PATHLOG>
+EZD void plog(const TraceArgs& a, size_t pix, int slot, int32_t tri, float t) {
+  if (PATHLOG) {
+    int slots = 1 + 2 * a.p.max_bounce;
+    a.log_tri[pix * slots + slot] = tri;
+    a.log_t[pix * slots + slot] = (tri >= 0) ? t : INF;
+  }
+}
+
+template <int INTEG, bool FULLCTR, bool PATHLOG>
+__global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int lds_stack[];
+  constexpr bool P5TRI = (INTEG >= 50);
+  const int tid = threadIdx.x;
+  const int blk = blockIdx.x % a.n_blocks;
+  const int fk = blockIdx.x / a.n_blocks;
+  const uint32_t frame = a.frame_first + (uint32_t)fk;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int2 org = a.blocks[blk];
+  const int x = org.x + (wave & 1) * 8 + (lane & 7);
+  const int y = org.y + (wave >> 1) * 8 + (lane >> 3);
+  int* stack = lds_stack + tid;
+  const DevScene& sc = a.sc;
+  const EzrtRenderParams& p = a.p;
+
+  Counters ctr = {0, 0, 0, 0, 0, 0, 0};
+  uint32_t samples = 0;
+  f3 colour = mk(0, 0, 0);
+  const bool active = pixel_owned(p, x, y);
+  if (active) {
+    samples = 1;
+    const size_t pix = (size_t)y * p.width + x;
+    if (PATHLOG) {
+      int slots = 1 + 2 * p.max_bounce;
+      for (int k = 0; k < slots; k++) {
+        a.log_tri[pix * slots + k] = -2;
+        a.log_t[pix * slots + k] = INF;
+      }
+    }
+    // main(): P5/fsh:315-318, 920-925
+    const uint32_t ix = (uint32_t)x, iy = (uint32_t)y;
+    uint32_t seed = (ix * 1973u + iy * 9277u + frame * 26699u) | 1u;
+    const float W = (float)p.width, H = (float)p.height;
+    float pixx = ((float)ix + 0.5f) / W * 2.0f - 1.0f;
+    float pixy = ((float)iy + 0.5f) / H * 2.0f - 1.0f;
+    float aax = (rnd(seed) - 0.5f) / W;
+    float aay = (rnd(seed) - 0.5f) / H;
+    float vx = pixx + aax, vy = pixy + aay, vz = -1.5f;
+    const float* m = p.camera_rotate;
+    f3 dir = mk(m[0] * vx + m[4] * vy + m[8] * vz, m[1] * vx + m[5] * vy + m[9] * vz,
+                m[2] * vx + m[6] * vy + m[10] * vz);
+    dir = normalize(dir);
+    f3 org3 = mk(p.eye[0], p.eye[1], p.eye[2]);
+
+    int32_t tri;
+    float t;
+    hit_bvh<FULLCTR, BLOCK>(sc, org3, dir, stack, tri, t, ctr);
+    plog<PATHLOG>(a, pix, 0, tri, t);
+    if (tri < 0) {
+      colour = hdr_color<FULLCTR>(sc, dir, p.env_clamp, ctr);
+    } else {
+      Hit hit;
+      shade_point<P5TRI>(sc, tri, t, org3, dir, hit);
+      const f3 Le0 = hit.m.emissive;
+      f3 Lo = mk(0, 0, 0), history = mk(1, 1, 1);
+      float cpu = 0.0f, cpv = 0.0f;
+      if (INTEG >= 50) cp_offsets(ix, iy, cpu, cpv);
+      const uint32_t gray = gray_code(frame + 1u);
+
+      for (int bounce = 0; bounce < p.max_bounce; bounce++) {
+        const f3 V = -hit.viewDir, N = hit.N;
+        if (INTEG == EZRT_INTEGRATOR_P5_MIS) {
+          // env importance sample + shadow ray: P5/fsh:819-842
+          float h1 = rnd(seed);
+          float h2 = rnd(seed);
+          f3 Lh = sample_hdr<FULLCTR>(sc, h1, h2, ctr);
+          if (dot(N, Lh) > 0.0f) {
+            int32_t st;
+            float stt;
+            hit_bvh<FULLCTR, BLOCK>(sc, hit.P, Lh, stack, st, stt, ctr);
+            plog<PATHLOG>(a, pix, 1 + 2 * bounce, st, stt);
+            if (st < 0) {
+              f3 color = hdr_color<FULLCTR>(sc, Lh, p.env_clamp, ctr);
+              float pdf_light = hdr_pdf<FULLCTR>(sc, Lh, ctr);
+              f3 f_r = brdf_evaluate<false>(V, N, Lh, mk(0, 0, 0), mk(0, 0, 0), hit.m);
+              float pdf_brdf = brdf_pdf(V, N, Lh, hit.m);
+              float w = mis_mix_weight(pdf_light, pdf_brdf);
+              Lo = Lo + (((history * w) * color) * f_r) * dot(N, Lh) / pdf_light;
+            }
+          }
+        }
+        // sample direction
+        f3 L;
+        float xi1, xi2;
+        if (INTEG >= 50) { // sobolVec2 + CP: P5/fsh:771-772, 845-846 (dims wrap at 8)
+          uint32_t d0 = ((uint32_t)bounce * 2u) & 7u, d1 = ((uint32_t)bounce * 2u + 1u) & 7u;
+          xi1 = cp_rotate(sobol(d0, gray), cpu);
+          xi2 = cp_rotate(sobol(d1, gray), cpv);
+        } else { // P3/fsh:109-114: z = rand() then phi = 2 pi rand()
+          xi1 = rnd(seed);
+          xi2 = rnd(seed);
+        }
+        float cosine, pdf;
+        f3 f_r;
+        if (INTEG == EZRT_INTEGRATOR_P5_MIS) {
+          float xi3 = rnd(seed);
+          L = sample_brdf(xi1, xi2, xi3, V, N, hit.m);
+          cosine = dot(N, L);
+          if (cosine <= 0.0f) break;
+        } else {
+          L = to_normal_hemisphere(sample_hemisphere(xi1, xi2), N);
+          pdf = 1.0f / (2.0f * PI);
+          cosine = ez_max(0.0f, dot(L, N));
+          if (INTEG == EZRT_INTEGRATOR_P3_DIFFUSE) {
+            f_r = hit.m.baseColor / PI;
+          } else {
+            f3 tangent, bitangent;
+            get_tangent(N, tangent, bitangent);
+            f_r = brdf_evaluate<INTEG == EZRT_INTEGRATOR_P4_DISNEY>(V, N, L, tangent, bitangent, hit.m);
+          }
+        }
+        int32_t nt;
+        float ntt;
+        hit_bvh<FULLCTR, BLOCK>(sc, hit.P, L, stack, nt, ntt, ctr);
+        plog<PATHLOG>(a, pix, 2 + 2 * bounce, nt, ntt);
+        if (INTEG == EZRT_INTEGRATOR_P5_MIS) {
+          f_r = brdf_evaluate<false>(V, N, L, mk(0, 0, 0), mk(0, 0, 0), hit.m);
+          pdf = brdf_pdf(V, N, L, hit.m);
+          if (pdf <= 0.0f) break;
+        }
+        if (nt < 0) {
+          f3 sky = hdr_color<FULLCTR>(sc, L, p.env_clamp, ctr);
+          if (INTEG == EZRT_INTEGRATOR_P5_MIS) {
+            float pdf_light = hdr_pdf<FULLCTR>(sc, L, ctr);
+            float w = mis_mix_weight(pdf, pdf_light);
+            Lo = Lo + (((history * w) * sky) * f_r) * cosine / pdf;
+          } else {
+            Lo = Lo + ((history * sky) * f_r) * cosine / pdf;
+          }
+          break;
+        }
+        Hit nh;
+        shade_point<P5TRI>(sc, nt, ntt, hit.P, L, nh);
+        Lo = Lo + ((history * nh.m.emissive) * f_r) * cosine / pdf;
+        history = history * (f_r * cosine / pdf);
+        hit = nh;
+      }
+      colour = Le0 + Lo;
+    }
+    if (PATHLOG) {
+      a.log_colour[pix * 3 + 0] = colour.x;
+      a.log_colour[pix * 3 + 1] = colour.y;
+      a.log_colour[pix * 3 + 2] = colour.z;
+    }
+  }
+  if (!PATHLOG) a.samples[((size_t)fk * a.n_blocks + blk) * BLOCK + tid] = make_float4(colour.x, colour.y, colour.z, 1.0f);
+
+  // counters: one atomic per wave per slot
+  unsigned long long r = wave_sum(ctr.rays), s = wave_sum(samples);
+  if (lane == 0) {
+    atomicAdd(&a.counters[EZRT_CTR_RAYS], r);
+    atomicAdd(&a.counters[EZRT_CTR_SAMPLES], s);
+  }
+  if (FULLCTR) {
+    unsigned long long v1 = wave_sum(ctr.pops), v2 = wave_sum(ctr.inner), v3 = wave_sum(ctr.tris),
+                       v4 = wave_sum(ctr.mats), v5 = wave_sum(ctr.envmap), v6 = wave_sum(ctr.envcache);
+    if (lane == 0) {
+      atomicAdd(&a.counters[EZRT_CTR_NODE_POPS], v1);
+      atomicAdd(&a.counters[EZRT_CTR_INNER_POPS], v2);
+      atomicAdd(&a.counters[EZRT_CTR_TRI_TESTS], v3);
+      atomicAdd(&a.counters[EZRT_CTR_MAT_FETCH], v4);
+      atomicAdd(&a.counters[EZRT_CTR_ENV_MAP], v5);
+      atomicAdd(&a.counters[EZRT_CTR_ENV_CACHE], v6);
+    }
+  }
+}
+
+// mix(lastColor, color, 1.0/float(frameCounter+1)): P5/fsh:943-947, in frame order.
+struct AccumArgs {
+  EzrtRenderParams p;
+  const int2* blocks;
+  int32_t n_blocks;
+  uint32_t frame_first, n_frames;
+  const float4* samples;
+  float4* accum; // [H][W] RGBA
+};
+__global__ __launch_bounds__(BLOCK) void accumulate_kernel(AccumArgs a) {
+  const int tid = threadIdx.x, blk = blockIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int2 org = a.blocks[blk];
+  const int x = org.x + (wave & 1) * 8 + (lane & 7);
+  const int y = org.y + (wave >> 1) * 8 + (lane >> 3);
+  if (!pixel_owned(a.p, x, y)) return;
+  const size_t pix = (size_t)y * a.p.width + x;
+  float4 last = a.accum[pix];
+  f3 mean = mk(last.x, last.y, last.z);
+  for (uint32_t k = 0; k < a.n_frames; k++) {
+    float4 c = a.samples[((size_t)k * a.n_blocks + blk) * BLOCK + tid];
+    uint32_t frame = a.frame_first + k;
+    if (frame == 0) {
+      mean = mk(c.x, c.y, c.z);
+    } else {
+      float w = 1.0f / (float)(frame + 1u);
+      mean = mix3(mean, mk(c.x, c.y, c.z), w);
+    }
+  }
+  a.accum[pix] = make_float4(mean.x, mean.y, mean.z, 1.0f);
+}
+
+__global__ void sobol_kernel(uint32_t index0, int n, int n_dims, float* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * n_dims) return;
+  int s = i / n_dims, d = i % n_dims;
+  out[i] = sobol((uint32_t)d, gray_code(index0 + (uint32_t)s));
+}
+
+// pass3.fsh:14-24 + P1/main.cpp:187-189
+__global__ void tonemap_kernel(const float4* rgba, int n, uint8_t* rgb8) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 c = rgba[i];
+  float lum = 0.3f * c.x + 0.6f * c.y + 0.1f * c.z;
+  float k = 1.0f + lum / 1.5f;
+  float ch[3] = {c.x, c.y, c.z};
+  for (int j = 0; j < 3; j++) {
+    float v = ch[j] * 1.0f / k;
+    v = ez_pow(v, 1.0f / 2.2f);
+    float q = ez_clamp(v * 255.0f, 0.0f, 255.0f);
+    if (!(q == q)) q = 0.0f;
+    rgb8[(size_t)i * 3 + j] = (uint8_t)(int)q;
+  }
+}
+
+struct QueryArgs {
+  DevScene sc;
+  const float* rays;
+  int n;
+  int32_t* tri;
+  float* t;
+  unsigned long long* counters;
+};
+template <bool FULLCTR>
+__global__ __launch_bounds__(BLOCK) void query_kernel(QueryArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int lds_stack[];
+  int i = blockIdx.x * BLOCK + threadIdx.x;
+  Counters ctr = {0, 0, 0, 0, 0, 0, 0};
+  if (i < a.n) {
+    const float* r = a.rays + (size_t)i * 6;
+    int32_t tri;
+    float t;
+    hit_bvh<FULLCTR, BLOCK>(a.sc, mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]), lds_stack + threadIdx.x, tri, t, ctr);
+    a.tri[i] = tri;
+    a.t[i] = (tri >= 0) ? t : INF;
+  }
+  unsigned long long rr = wave_sum(ctr.rays);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&a.counters[EZRT_CTR_RAYS], rr);
+  if (FULLCTR) {
+    unsigned long long v1 = wave_sum(ctr.pops), v2 = wave_sum(ctr.inner), v3 = wave_sum(ctr.tris), v4 = wave_sum(ctr.mats);
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&a.counters[EZRT_CTR_NODE_POPS], v1);
+      atomicAdd(&a.counters[EZRT_CTR_INNER_POPS], v2);
+      atomicAdd(&a.counters[EZRT_CTR_TRI_TESTS], v3);
+      atomicAdd(&a.counters[EZRT_CTR_MAT_FETCH], v4);
+    }
+  }
+}
+
+__global__ void math_kernel(int op, const float* a, const float* b, int n, float* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x = a[i], y = b[i], r;
+  switch (op) {
+    case 0: r = ez_sin(x); break;
+    case 1: r = ez_cos(x); break;
+    case 2: r = ez_atan2(x, y); break;
+    case 3: r = ez_asin(x); break;
+    case 4: r = ez_log(x); break;
+    case 5: r = ez_exp(x); break;
+    case 6: r = ez_pow(x, y); break;
+    case 7: r = __builtin_sqrtf(x); break;
+    case 8: r = x / y; break;
+    default: {
+      uint32_t sd = __float_as_uint(x);
+      r = rnd(sd);
+    }
+  }
+  out[i] = r;
+}
+
+} // namespace ezd

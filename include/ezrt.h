@@ -1,0 +1,153 @@
+/* ezrt.h -- the drop-in C ABI for EzRT's per-pixel trace on MI355X.
+ *
+ * The reference (AKGWSB/EzRT) has no plugin/FFI interface: each chapter is a
+ * closed main().  The de-facto boundary between its host code and its trace is
+ * the GL resource set created in main() and bound in display():
+ *
+ *   triangles  float[nTri*36]   12 RGB32F texels / triangle   P5/main.cpp:843-862,878-884
+ *   nodes      float[nNodes*12]  4 RGB32F texels / node        P5/main.cpp:864-871,887-893
+ *   hdrMap     float[W*H*3]     row 0 = top scanline           P5/main.cpp:896-899
+ *   hdrCache   float[W*H*3]     importance-sampling cache      P5/main.cpp:901-906
+ *   uniforms   frameCounter,width,height,eye,cameraRotate,hdrResolution
+ *                                                              P5/main.cpp:717-720,919-923
+ *   lastFrame  RGBA32F WxH running mean, origin bottom-left    P5/main.cpp:926-929, fsh:943-947
+ *
+ * Every entry point below replaces one of those GL interactions; the cited
+ * lines are what a maintainer would delete when binding this library instead
+ * (INTEGRATION.md shows the stub).  Plain pointers and sizes only; caller owns
+ * all host buffers; the library copies at create/set time.  All functions
+ * return 0 on success or a negative EZRT_ERR_* code and never exit().
+ *
+ * The same ABI is implemented twice: libezrt_hip.so (hand-written gfx950 HIP
+ * kernels -- the product) and oracle/libezrt_oracle.so (plain-C restatement of
+ * the reference arithmetic -- test infrastructure only).
+ */
+#ifndef EZRT_H
+#define EZRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EZRT_OK 0
+#define EZRT_ERR_INVALID (-1)   /* bad argument / malformed scene arrays          */
+#define EZRT_ERR_DEVICE (-2)    /* HIP runtime error (see ezrt_last_error)        */
+#define EZRT_ERR_UNSUPPORTED (-3) /* valid but outside this build's limits        */
+#define EZRT_ERR_NOMEM (-4)
+
+/* Record sizes of the reference encoding (P3/fsh:27-28: SIZE_TRIANGLE 12,
+ * SIZE_BVHNODE 4 texels of 3 floats). */
+#define EZRT_TRI_FLOATS 36
+#define EZRT_NODE_FLOATS 12
+
+/* Integrators = the pathTracing variants of the three GPU chapters. */
+#define EZRT_INTEGRATOR_P3_DIFFUSE 3  /* P3/fsh:376-413  rand() hemisphere, Lambert, env clamp   */
+#define EZRT_INTEGRATOR_P4_DISNEY 4   /* P4/fsh:478-517  rand() hemisphere, anisotropic Disney   */
+#define EZRT_INTEGRATOR_P5_SOBOL 50   /* P5/fsh:762-807  Sobol+CP hemisphere, isotropic Disney   */
+#define EZRT_INTEGRATOR_P5_MIS 51     /* P5/fsh:810-890  BRDF + env importance sampling, MIS     */
+
+#define EZRT_FILTER_NEAREST 0 /* P3/P4 textures */
+#define EZRT_FILTER_BILINEAR 1 /* P5/main.cpp:196-197 GL_LINEAR */
+
+typedef struct EzrtScene EzrtScene; /* opaque, device-resident */
+
+/* Replaces the uniform block + FBO of display() (P5/main.cpp:697-748). */
+typedef struct EzrtRenderParams {
+  int32_t width, height;      /* uniforms width/height = image size                  */
+  int32_t x0, y0, x1, y1;     /* half-open pixel rect to render; (0,0,w,h) = all     */
+  uint32_t frame0;            /* first frameCounter value (P5/main.cpp:719)          */
+  uint32_t spp;               /* number of frames = samples per pixel                */
+  int32_t max_bounce;         /* P3: 2, P4: 4, P5: 2 (fsh:436 / 540 / 935)           */
+  int32_t integrator;         /* EZRT_INTEGRATOR_*                                   */
+  float eye[3];               /* uniform eye                                         */
+  float camera_rotate[16];    /* uniform cameraRotate, column-major (GL_FALSE)       */
+  float env_clamp;            /* >0: env radiance = min(c, env_clamp) (P3/fsh:154)   */
+  int32_t tile_w, tile_h;     /* tile grid used for multi-GPU sharding (0 = 32)      */
+  int32_t shard_index;        /* this caller renders tiles with                      */
+  int32_t shard_count;        /*   tile_id % shard_count == shard_index (0 or 1=all) */
+} EzrtRenderParams;
+
+/* Counter slots of ezrt_counters(): exact integers, the inputs of the
+ * algorithmic-bytes roofline figure. */
+enum {
+  EZRT_CTR_RAYS = 0,      /* hitBVH invocations                                    */
+  EZRT_CTR_NODE_POPS = 1, /* P: getBVHNode(top)                P5/fsh:266           */
+  EZRT_CTR_INNER_POPS = 2,/* I: two child fetches              P5/fsh:280-287       */
+  EZRT_CTR_TRI_TESTS = 3, /* T: getTriangle + hitTriangle      P5/fsh:243-244       */
+  EZRT_CTR_MAT_FETCH = 4, /* M: getMaterial on closer hit      P5/fsh:247           */
+  EZRT_CTR_SAMPLES = 5,   /* pixel-samples (fragment invocations)                  */
+  EZRT_CTR_ENV_MAP = 6,   /* texture2D(hdrMap)                                     */
+  EZRT_CTR_ENV_CACHE = 7, /* texture2D(hdrCache)                                   */
+  EZRT_CTR_COUNT = 8
+};
+
+/* glBufferData+glTexBuffer of the two TBOs (P5/main.cpp:878-893).  tri =
+ * nTri*36 floats, nodes = nNodes*12 floats, node 0 dummy, root = node 1. */
+int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nodes, EzrtScene** out);
+void ezrt_scene_destroy(EzrtScene* s);
+
+/* glTexImage2D of hdrMap and hdrCache + hdrResolution (P5/main.cpp:896-906).
+ * cache may be NULL (integrators 3/4/50 never read it). */
+int ezrt_scene_set_env(EzrtScene* s, const float* hdr, const float* cache, int w, int h, int filter);
+
+/* One call = spp iterations of display()'s pass1+pass2 (P5/main.cpp:743-744).
+ * accum: host RGBA32F [height][width][4], row 0 = bottom; in = running mean
+ * after frame0 samples (ignored when frame0 == 0), out = after frame0+spp. */
+int ezrt_render(EzrtScene* s, const EzrtRenderParams* p, float* accum_rgba);
+
+/* Same, but accum is a device pointer (HBM-resident lastFrame) and the work is
+ * enqueued on `stream` (a hipStream_t, NULL = default stream) without a host
+ * sync.  In the oracle library "device" memory is host memory. */
+int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_rgba_dev, void* stream);
+
+/* Parity audit: render exactly one frame (p->frame0, spp ignored) and report
+ * for every pixel of the rect and every ray slot of its path the hit triangle
+ * id (-1 = miss, -2 = ray not shot) and distance.  Slots: 0 = primary; for
+ * bounce b: 1+2b = env shadow ray (integrator 51 only), 2+2b = bounce ray.
+ * tri_id/t_hit: host [height][width][1+2*max_bounce].  colour: host RGB
+ * [height][width][3] sample radiance (before accumulation), may be NULL. */
+int ezrt_render_paths(EzrtScene* s, const EzrtRenderParams* p, int32_t* tri_id, float* t_hit, float* colour);
+
+/* hitBVH on caller-supplied rays (P2/main.cpp:581-588 probe; P5/fsh:254-306).
+ * rays: n*6 floats (origin, direction).  tri_id = -1 on miss. */
+int ezrt_query_hits(EzrtScene* s, const float* rays_od6, int n_rays, int32_t* tri_id, float* t_hit);
+
+/* pass3: toneMapping(c, 1.5) + pow(1/2.2) (P5/shaders/pass3.fsh:14-24), then
+ * P1-style 8-bit quantisation clamp(x*255, 0, 255) (P1/main.cpp:187-189).
+ * rgba: host [n_pixels][4] -> rgb8 [n_pixels][3]. */
+int ezrt_tonemap(const float* rgba, int n_pixels, uint8_t* rgb8);
+
+/* Sobol generator of the trace (P5/fsh:351-376): out[i*n_dims+d] =
+ * sobol(d, grayCode(index0+i)), d < n_dims <= 8. */
+int ezrt_sobol(uint32_t index0, int n, int n_dims, float* out);
+
+/* Instrumentation: level 0 counts rays + samples only (timed runs), level 1
+ * also counts P/I/T/M and env lookups.  Counters accumulate until reset. */
+int ezrt_set_instrumentation(EzrtScene* s, int level);
+int ezrt_counters(EzrtScene* s, uint64_t out[EZRT_CTR_COUNT]);
+int ezrt_counters_reset(EzrtScene* s);
+
+/* Device time of the kernels of the last ezrt_render* call on this scene, in
+ * milliseconds, measured with hipEvents on the launch stream; total and the
+ * trace kernel alone.  Forces a sync on the events. */
+int ezrt_last_render_ms(EzrtScene* s, float* total_ms, float* trace_kernel_ms, int* n_trace_launches);
+
+/* Scene statistics computed at create time: [0] nTri [1] nNodes [2] tree depth
+ * [3] nLeaves [4] max leaf size [5] device bytes. */
+int ezrt_scene_stats(EzrtScene* s, int64_t out[6]);
+
+/* Evaluate the deterministic math definitions on the implementation's compute
+ * device (GPU for libezrt_hip) for the bit-equality test.  op: 0 sin, 1 cos,
+ * 2 atan2(a,b), 3 asin, 4 log, 5 exp, 6 pow(a,b), 7 sqrt, 8 a/b, 9 wang-hash
+ * float of uint bits(a). */
+int ezrt_debug_math(int op, const float* a, const float* b, int n, float* out);
+
+const char* ezrt_last_error(void);
+const char* ezrt_backend(void); /* "hip:gfx950" or "oracle:cpu" */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EZRT_H */
