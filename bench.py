@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on its config: Mrays/s at fixed spp.
+
+Workload (config.workload "C2"): the P3 scene with the Stanford Bunny subdivided to ~70k triangles
+(79 820 total), SAH BVH leaf 8, 512x512, integrator 50 (P5 pathTracing: Sobol + Cranley-Patterson
+hemisphere sampling, Disney BRDF), 4 bounces, 64 spp, procedural 1024x512 env map.  One "step" =
+one full render of that frame (64 spp) through libezrt_hip.so; scene, env map and the frame buffer
+are resident in HBM before the timed region.  ray := one hitBVH call, counted by the kernels.
+
+N > 1: one process per GPU (torchrun); the image is split into 16x16 tiles dealt round-robin to the
+ranks (scene replicated), each rank traces its tiles, then ONE gather of the packed tiles to rank 0
+over RCCL closes the frame.  Total work is fixed => "scaling": "strong".
+
+Prints one JSON line on rank 0 (contract in the task statement) with `roofline` and, at N = 1,
+`cpu_baseline` (the CPU oracle timed on a bounded sample of the same workload).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def alg_bytes(c, bilinear=True):
+    """bytes(ray) = 48 P + 96 I + 72 T + 72 M in the reference's record sizes,
+    + 32 B per pixel-sample (lastFrame read + write) + 48/12 B per env-map / cache lookup."""
+    tex = 48 if bilinear else 12
+    return (48 * c["node_pops"] + 96 * c["inner_pops"] + 72 * c["tri_tests"] + 72 * c["mat_fetch"]
+            + 32 * c["samples"] + tex * (c["env_map"] + c["env_cache"]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--bounces", type=int, default=4)
+    ap.add_argument("--integrator", type=int, default=50)
+    ap.add_argument("--subdiv", type=int, default=2)
+    ap.add_argument("--tile", type=int, default=16)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time (0 = skip)")
+    ap.add_argument("--save-png", default="")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the trace has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from ezrt_amd import scene as S, scenes, tiles, trace
+    hip = trace.hip()  # after torch: shares torch's HIP runtime (same soname)
+
+    t_build = time.perf_counter()
+    want_cache = args.integrator == 51
+    bs = scenes.bunny_scene(subdiv=args.subdiv, want_cache=want_cache)
+    t_build = time.perf_counter() - t_build
+    sc = bs.upload(hip)
+    eye, cam = S.camera(0, 0, 4)
+    W, H = args.width, args.height
+    p = trace.make_params(W, H, eye, cam, args.integrator, args.bounces, spp=args.spp, tile=(args.tile, args.tile),
+                          shard=(rank, world))
+    accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    plan = tiles.TilePlan(W, H, args.tile, args.tile, world) if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        sc.render_device(p, accum.data_ptr(), stream)
+        if world > 1:
+            return tiles.gather_frame(accum, plan, rank, dist)
+        return accum
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    sc.counters_reset()
+    trace_ms = []
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        final = step()
+        if world == 1:
+            trace_ms.append(sc.last_render_ms())
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    rays_local = sc.counters()["rays"]
+    tt = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+    rays_total = float(tt[1])
+    rays_per_step = rays_total / max(1, args.steps)
+    value = rays_total / elapsed / 1e6
+
+    out = {
+        "metric": "Mrays/s at fixed spp (Bunny ~70k tris, 4 bounces)",
+        "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C2: P3 scene, Stanford Bunny subdivided x%d (%d tris, %d BVH nodes, SAH leaf 8), "
+                               "%dx%d, integrator %d, %d bounces, %d spp, procedural 1024x512 env"
+                               % (args.subdiv, bs.tri.shape[0], bs.nodes.shape[0], W, H, args.integrator, args.bounces,
+                                  args.spp),
+                   "rays_per_step": int(rays_per_step), "ray_definition": "one hitBVH call",
+                   "parallelism": "tiles%dx%d round-robin over %d GPU(s), 1 RCCL gather/frame" % (args.tile, args.tile, world),
+                   "scene_build_s": round(t_build, 3)},
+    }
+
+    if rank == 0 and world == 1:
+        # ---- roofline of the dominant kernel (trace_kernel): algorithmic bytes / launch duration
+        sc.set_instrumentation(1)
+        sc.counters_reset()
+        sc.render_device(p, accum.data_ptr(), stream)
+        torch.cuda.synchronize()
+        c = sc.counters()
+        _, _, n_launch = sc.last_render_ms()
+        sc.set_instrumentation(0)
+        bytes_step = alg_bytes(c, bilinear=(bs.env_filter == 1))
+        ms_trace = sum(m[1] for m in trace_ms) / len(trace_ms)      # per step, all trace launches
+        launches = max(1, trace_ms[0][2])
+        ach = bytes_step / (ms_trace * 1e-3) / 1e9
+        out["roofline"] = {
+            "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+            "kernel": "trace_kernel<%d,false,false>" % args.integrator,
+            "alg_bytes_per_launch": int(bytes_step // launches), "alg_bytes_per_ray": round(bytes_step / c["rays"], 1),
+            "launch_ms": round(ms_trace / launches, 4), "launches_per_step": launches,
+            "counters_per_step": {k: c[k] for k in ("rays", "node_pops", "inner_pops", "tri_tests", "mat_fetch", "samples", "env_map", "env_cache")},
+            "frac_of_measured_copy_peak_6290": round(ach / 6290.0, 5),
+        }
+        # ---- CPU baseline: the oracle (a port, not the reference binary) on a bounded sample
+        if args.cpu_seconds > 0:
+            from ezrt_amd import _abi
+            opath = os.path.join(ROOT, "oracle", "libezrt_oracle.so")
+            ora = trace.TraceLib(_abi.declare_trace_abi(ctypes.CDLL(opath)))
+            so = bs.upload(ora)
+            cores = os.cpu_count() or 1
+            img = np.zeros((H, W, 4), np.float32)
+            t1 = time.perf_counter()
+            so.render(trace.make_params(W, H, eye, cam, args.integrator, args.bounces, spp=1), img)
+            d1 = time.perf_counter() - t1
+            n = int(max(1, min(args.spp - 1, args.cpu_seconds / max(d1, 1e-3))))
+            so.counters_reset()
+            t1 = time.perf_counter()
+            so.render(trace.make_params(W, H, eye, cam, args.integrator, args.bounces, spp=n, frame0=1), img)
+            dn = time.perf_counter() - t1
+            cr = so.counters()["rays"]
+            gpu_img = final.detach().cpu().numpy()
+            out["cpu_baseline"] = {"value": round(cr / dn / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                                   "sample": "frames 1..%d of the same %dx%d workload (%d rays, %.1f s), OpenMP over rows"
+                                             % (n, W, H, cr, dn)}
+            if n + 1 == args.spp:
+                out["cpu_baseline"]["linf_vs_gpu"] = float(np.abs(gpu_img - img).max())
+
+    if rank == 0:
+        if args.save_png:
+            from PIL import Image
+            rgb = hip.tonemap(final.detach().cpu().numpy().reshape(-1, 4)).reshape(H, W, 3)[::-1]
+            Image.fromarray(rgb).save(args.save_png)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,79 @@
+"""Image-space sharding for the multi-GPU path.
+
+Pixels are independent, so a frame is cut into tile_w x tile_h tiles dealt round-robin to the
+ranks (tile_id % world == rank -- the same rule `EzrtRenderParams.shard_*` applies inside the
+kernels); every rank traces all spp of its tiles into its own full-size frame buffer, and the
+frame is closed by ONE gather of the packed tiles to rank 0 (RCCL over xGMI when the tensors are
+on GPUs: 7 peers -> root on 7 distinct links).  No other collective touches the data path.
+
+torch is plumbing here (device tensors + torch.distributed); the functions also run on CPU tensors
+with the gloo backend, which is how tests/test_tiles_gloo.py covers world_size 2 without GPUs.
+"""
+import torch
+
+
+class TilePlan:
+    def __init__(self, width, height, tile_w, tile_h, world):
+        self.width, self.height = int(width), int(height)
+        self.tile_w, self.tile_h = int(tile_w), int(tile_h)
+        self.world = int(world)
+        self.tiles_x = (self.width + self.tile_w - 1) // self.tile_w
+        self.tiles_y = (self.height + self.tile_h - 1) // self.tile_h
+        self.n_tiles = self.tiles_x * self.tiles_y
+        self.per_rank = (self.n_tiles + self.world - 1) // self.world
+        self._ids = {}
+
+    def owner(self, tile_id):
+        return tile_id % self.world
+
+    def tile_ids(self, rank, device=None):
+        """Tile ids owned by `rank`, padded (by repeating the last id) to `per_rank` entries."""
+        key = (rank, str(device))
+        if key not in self._ids:
+            ids = list(range(rank, self.n_tiles, self.world))
+            n_real = len(ids)
+            while len(ids) < self.per_rank:
+                ids.append(ids[-1] if ids else 0)
+            self._ids[key] = (torch.tensor(ids, dtype=torch.long, device=device), n_real)
+        return self._ids[key]
+
+    # image [H, W, C] <-> tiles [n_tiles, tile_h, tile_w, C]
+    def to_tiles(self, img):
+        H, W, C = img.shape
+        ph, pw = self.tiles_y * self.tile_h - H, self.tiles_x * self.tile_w - W
+        if ph or pw:
+            img = torch.nn.functional.pad(img, (0, 0, 0, pw, 0, ph))
+        t = img.reshape(self.tiles_y, self.tile_h, self.tiles_x, self.tile_w, C).permute(0, 2, 1, 3, 4)
+        return t.reshape(self.n_tiles, self.tile_h, self.tile_w, C)
+
+    def from_tiles(self, tiles):
+        C = tiles.shape[-1]
+        t = tiles.reshape(self.tiles_y, self.tiles_x, self.tile_h, self.tile_w, C).permute(0, 2, 1, 3, 4)
+        img = t.reshape(self.tiles_y * self.tile_h, self.tiles_x * self.tile_w, C)
+        return img[: self.height, : self.width]
+
+    def pack(self, img, rank):
+        ids, _ = self.tile_ids(rank, img.device)
+        return self.to_tiles(img).index_select(0, ids).contiguous()
+
+    def unpack(self, packed_per_rank):
+        """packed_per_rank[r] = what rank r packed -> the full frame."""
+        first = packed_per_rank[0]
+        tiles = torch.zeros((self.n_tiles, self.tile_h, self.tile_w, first.shape[-1]), dtype=first.dtype,
+                            device=first.device)
+        for r, packed in enumerate(packed_per_rank):
+            ids, n_real = self.tile_ids(r, first.device)
+            tiles[ids[:n_real]] = packed[:n_real]
+        return self.from_tiles(tiles)
+
+
+def gather_frame(accum, plan, rank, dist, dst=0):
+    """Close a frame: one gather of every rank's packed tiles to `dst`.  Returns the assembled
+    [H, W, C] frame on `dst` and the rank's own buffer elsewhere."""
+    packed = plan.pack(accum, rank)
+    if rank == dst:
+        bufs = [torch.empty_like(packed) for _ in range(plan.world)]
+        dist.gather(packed, gather_list=bufs, dst=dst)
+        return plan.unpack(bufs)
+    dist.gather(packed, gather_list=None, dst=dst)
+    return accum

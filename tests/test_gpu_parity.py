@@ -1,0 +1,202 @@
+"""Parity tests proper: the gfx950 HIP path (through the C ABI) against the CPU oracle on the
+same seeded inputs.  Bar (BASELINE.json north_star): hit-triangle ids bit-exact, radiance within
+1e-4 per-channel L-inf -- the arithmetic contract actually makes both bit-exact, which
+the tests report and assert where stated."""
+import numpy as np
+import pytest
+
+from ezrt_amd import scene as S
+from ezrt_amd import scenes, trace
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # per-channel L-inf on radiance, BASELINE.json north_star
+INF = np.float32(114514.0)
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_hip_library_is_the_backend(hip):
+    assert hip.backend() == "hip:gfx950"
+
+
+def test_detmath_is_bit_identical_on_host_and_device(hip, oracle):
+    """The arithmetic contract: + - * / sqrt, int<->float and the det-math built-ins give the same
+    bits on x86-64 and gfx950."""
+    rng = np.random.default_rng(0)
+    n = 1 << 18
+    x = rng.uniform(-7, 7, n).astype(np.float32)
+    y = rng.uniform(-7, 7, n).astype(np.float32)
+    u = rng.uniform(-1.0001, 1.0001, n).astype(np.float32)
+    pos = np.exp(rng.uniform(-30, 30, n)).astype(np.float32)
+    small = np.concatenate([rng.uniform(0, 1e-37, n // 2), rng.uniform(0, 1, n // 2)]).astype(np.float32)
+    cases = [(0, x, None), (1, x, None), (2, x, y), (3, u, None), (4, pos, None), (5, x * 10, None),
+             (6, np.abs(u) * 0.01 + 1e-6, np.abs(y) / 7), (7, pos, None), (7, small, None), (8, x, y), (8, pos, small + 1e-30),
+             (9, rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32), None)]
+    for op, a, b in cases:
+        g, o = hip.debug_math(op, a, b), oracle.debug_math(op, a, b)
+        same = _bits(g) == _bits(o)
+        both_nan = np.isnan(g) & np.isnan(o)
+        assert (same | both_nan).all(), "op %d: %d mismatches" % (op, int((~(same | both_nan)).sum()))
+
+
+def test_query_hits_parity(hip, oracle, bunny_small):
+    from test_oracle import camera_rays, random_rays
+    rays = np.concatenate([camera_rays(20000, 1), random_rays(20000, 2)])
+    sg, so = bunny_small.upload(hip), bunny_small.upload(oracle)
+    tg, dg = sg.query_hits(rays)
+    to, do = so.query_hits(rays)
+    assert np.array_equal(tg, to)
+    assert np.array_equal(_bits(dg), _bits(do))
+    assert 0.2 < (tg >= 0).mean() < 0.9
+
+
+@pytest.mark.parametrize("integ,bounces,clamp", [(3, 2, 10.0), (4, 4, 0.0), (50, 4, 0.0), (51, 2, 0.0)])
+def test_path_audit_every_ray_of_every_pixel(hip, oracle, bunny_small, integ, bounces, clamp):
+    """Per pixel-sample discrete-decision audit: the triangle id and distance of every ray of the
+    path (primary, env shadow rays, bounce rays) and the sample radiance."""
+    sg, so = bunny_small.upload(hip), bunny_small.upload(oracle)
+    eye, cam = S.camera(15, 8, 3.2)
+    for frame in (0, 5):
+        p = trace.make_params(96, 80, eye, cam, integ, bounces, frame0=frame, env_clamp=clamp)
+        tg, dg, cg = sg.render_paths(p)
+        to, do, co = so.render_paths(p)
+        assert np.array_equal(tg, to), "hit triangle ids differ on %d rays" % int((tg != to).sum())
+        assert np.array_equal(_bits(dg), _bits(do))
+        err = np.abs(cg - co)
+        assert np.nanmax(err) < TOL
+        assert np.array_equal(_bits(cg), _bits(co)), "radiance not bit-exact: Linf %g" % np.nanmax(err)
+        assert (tg[..., 0] >= 0).mean() > 0.3
+
+
+@pytest.mark.parametrize("integ,bounces,clamp", [(3, 2, 10.0), (4, 4, 0.0), (50, 4, 0.0), (51, 2, 0.0)])
+def test_render_parity_and_counters(hip, oracle, bunny_small, integ, bounces, clamp):
+    sg, so = bunny_small.upload(hip), bunny_small.upload(oracle)
+    eye, cam = S.camera(0, 0, 4)
+    sg.set_instrumentation(1)
+    so.set_instrumentation(1)
+    p = trace.make_params(128, 128, eye, cam, integ, bounces, spp=6, env_clamp=clamp)
+    ig, io = sg.render(p), so.render(p)
+    assert np.abs(ig - io).max() < TOL
+    assert np.array_equal(_bits(ig), _bits(io))
+    assert sg.counters() == so.counters()
+    # level-0 instrumentation counts the same rays and nothing else
+    sg.set_instrumentation(0)
+    sg.counters_reset()
+    ig0 = sg.render(p)
+    assert np.array_equal(_bits(ig0), _bits(ig))
+    c0 = sg.counters()
+    assert c0["rays"] == so.counters()["rays"] and c0["node_pops"] == 0
+
+
+def test_p5_scene_mirror_floor_parity(hip, oracle):
+    """P5 materials: metallic clear-coated body on a near-mirror floor (GTR1/GTR2 lobes, pow/log)."""
+    bs = scenes.p5_scene(subdiv=0)
+    sg, so = bs.upload(hip), bs.upload(oracle)
+    eye, cam = S.camera(90, 10, 2)
+    p = trace.make_params(96, 96, eye, cam, 51, 2, spp=4)
+    ig, io = sg.render(p), so.render(p)
+    assert np.nanmax(np.abs(ig - io)) < TOL
+    assert np.array_equal(_bits(ig), _bits(io))
+    tg, dg, _ = sg.render_paths(p)
+    to, do, _ = so.render_paths(p)
+    assert np.array_equal(tg, to) and np.array_equal(_bits(dg), _bits(do))
+
+
+def test_cornell_and_median_builder_parity(hip, oracle):
+    """C1 scene (12 triangles: root is an inner node over two leaves) and a median-split tree."""
+    eye, cam = S.camera(0, 0, 4)
+    for bs in (scenes.cornell_scene(), scenes.bunny_scene(subdiv=0, sah=False, leaf_n=3)):
+        sg, so = bs.upload(hip), bs.upload(oracle)
+        p = trace.make_params(64, 64, eye, cam, 3, 4, spp=2, env_clamp=10.0)
+        assert np.array_equal(_bits(sg.render(p)), _bits(so.render(p)))
+
+
+def test_single_leaf_scene(hip, oracle):
+    """nTri <= leaf size: the root itself is a leaf."""
+    bs = scenes.cornell_scene(leaf_n=16)
+    assert bs.nodes.shape[0] == 2
+    sg, so = bs.upload(hip), bs.upload(oracle)
+    eye, cam = S.camera(0, 0, 4)
+    p = trace.make_params(32, 32, eye, cam, 50, 3, spp=2)
+    assert np.array_equal(_bits(sg.render(p)), _bits(so.render(p)))
+
+
+def test_decompositions_reproduce_the_full_image(hip, bunny_small):
+    """Ragged sizes, pixel rects, frame-range splits and round-robin tile shards are bit-identical
+    to one full render (so the N-GPU image equals the 1-GPU image)."""
+    sg = bunny_small.upload(hip)
+    eye, cam = S.camera(20, 10, 3)
+    W, H = 203, 117  # not multiples of 16
+    full = sg.render(trace.make_params(W, H, eye, cam, 51, 2, spp=5))
+    part = sg.render(trace.make_params(W, H, eye, cam, 51, 2, spp=2, frame0=0))
+    part = sg.render(trace.make_params(W, H, eye, cam, 51, 2, spp=3, frame0=2), part)
+    assert np.array_equal(_bits(full), _bits(part))
+    img = np.zeros((H, W, 4), np.float32)
+    sg.render(trace.make_params(W, H, eye, cam, 51, 2, spp=5, rect=(0, 0, 77, H)), img)
+    sg.render(trace.make_params(W, H, eye, cam, 51, 2, spp=5, rect=(77, 0, W, H)), img)
+    assert np.array_equal(_bits(full), _bits(img))
+    for tile in ((32, 32), (8, 8), (24, 40)):
+        img = np.zeros((H, W, 4), np.float32)
+        for r in range(8):
+            sg.render(trace.make_params(W, H, eye, cam, 51, 2, spp=5, tile=tile, shard=(r, 8)), img)
+        assert np.array_equal(_bits(full), _bits(img)), tile
+
+
+def test_empty_work_and_errors(hip, bunny_small):
+    sg = bunny_small.upload(hip)
+    eye, cam = S.camera()
+    img = np.full((16, 16, 4), 7.0, np.float32)
+    sg.render(trace.make_params(16, 16, eye, cam, 50, 4, spp=0), img)
+    assert (img == 7.0).all()
+    sg.render(trace.make_params(16, 16, eye, cam, 50, 4, spp=1, rect=(3, 3, 3, 9)), img)
+    assert (img == 7.0).all()
+    with pytest.raises(trace.TraceError, match="integrator"):
+        sg.render(trace.make_params(8, 8, eye, cam, 7, 2))
+    bad = bunny_small.nodes.copy()
+    bad[1, 0] = 0
+    with pytest.raises(trace.TraceError, match="children"):
+        hip.scene_create(bunny_small.tri, bad)
+    sc = hip.scene_create(bunny_small.tri, bunny_small.nodes)
+    with pytest.raises(trace.TraceError, match="cache"):
+        sc.render(trace.make_params(8, 8, eye, cam, 51, 2))
+
+
+def test_tonemap_parity(hip, oracle):
+    rng = np.random.default_rng(3)
+    rgba = rng.uniform(0, 8, (4096, 4)).astype(np.float32)
+    assert np.array_equal(hip.tonemap(rgba), oracle.tonemap(rgba))
+
+
+def test_full_size_bunny_70k_properties_and_sampled_parity(hip, oracle):
+    """BASELINE.json configs[1] at full size (79 820 triangles, 512x512, 4 bounces): the oracle
+    cannot render 64 spp of it in seconds, so (a) tile-shard union == full render, (b) frame split
+    == full, (c) traversal counters and a 64x64 crop of 2 frames bit-equal the oracle."""
+    bs = scenes.bunny_scene(subdiv=2)
+    assert bs.tri.shape[0] == 79488 + 12 + 320
+    sg = bs.upload(hip)
+    eye, cam = S.camera(0, 0, 4)
+    W = H = 512
+    full = sg.render(trace.make_params(W, H, eye, cam, 50, 4, spp=8))
+    assert np.isfinite(full).all()
+    img = np.zeros((H, W, 4), np.float32)
+    for r in range(8):
+        sg.render(trace.make_params(W, H, eye, cam, 50, 4, spp=8, shard=(r, 8)), img)
+    assert np.array_equal(_bits(full), _bits(img))
+    part = sg.render(trace.make_params(W, H, eye, cam, 50, 4, spp=3))
+    part = sg.render(trace.make_params(W, H, eye, cam, 50, 4, spp=5, frame0=3), part)
+    assert np.array_equal(_bits(full), _bits(part))
+    so = bs.upload(oracle)
+    rect = (224, 150, 288, 214)  # across the bunny
+    pc = trace.make_params(W, H, eye, cam, 50, 4, spp=2, rect=rect)
+    sg.set_instrumentation(1)
+    so.set_instrumentation(1)
+    sg.counters_reset()
+    a = sg.render(pc, np.zeros((H, W, 4), np.float32))
+    b = so.render(pc, np.zeros((H, W, 4), np.float32))
+    assert np.array_equal(_bits(a), _bits(b))
+    assert sg.counters() == so.counters()
+    crop = full[rect[1]:rect[3], rect[0]:rect[2]]
+    assert crop[..., :3].max() > 0.5
