@@ -146,18 +146,37 @@ def main():
         c = sc.counters()
         _, _, n_launch = sc.last_render_ms()
         sc.set_instrumentation(0)
+        # Dominant kernel = traceq_kernel (persistent hitBVH over a ray queue, 1 + max_bounce launches
+        # per step).  Its algorithmic bytes are the traversal terms 48 P + 96 I + 72 T + 72 M; the
+        # remaining terms (32 B/sample, env texels) belong to the shade/accumulate kernels and are
+        # reported with the whole-step figure.
+        bytes_trace = 48 * c["node_pops"] + 96 * c["inner_pops"] + 72 * c["tri_tests"] + 72 * c["mat_fetch"]
         bytes_step = alg_bytes(c, bilinear=(bs.env_filter == 1))
-        ms_trace = sum(m[1] for m in trace_ms) / len(trace_ms)      # per step, all trace launches
+        ms_total = sum(m[0] for m in trace_ms) / len(trace_ms)      # all kernels of a step (hipEvents)
+        ms_trace = sum(m[1] for m in trace_ms) / len(trace_ms)      # traceq launches of a step
         launches = max(1, trace_ms[0][2])
-        ach = bytes_step / (ms_trace * 1e-3) / 1e9
+        ach = bytes_trace / (ms_trace * 1e-3) / 1e9
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "latest_pmc.json")
+        if os.path.exists(pmc_path):
+            try:
+                pm = json.load(open(pmc_path))
+                traffic = pm["traceq_hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
         out["roofline"] = {
             "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
-            "kernel": "trace_kernel<%d,false,false>" % args.integrator,
-            "alg_bytes_per_launch": int(bytes_step // launches), "alg_bytes_per_ray": round(bytes_step / c["rays"], 1),
+            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "kernel": "ezd::traceq_kernel<false,6>",
+            "alg_bytes_per_launch": int(bytes_trace // launches), "alg_bytes_per_ray": round(bytes_trace / c["rays"], 1),
             "launch_ms": round(ms_trace / launches, 4), "launches_per_step": launches,
             "counters_per_step": {k: c[k] for k in ("rays", "node_pops", "inner_pops", "tri_tests", "mat_fetch", "samples", "env_map", "env_cache")},
             "frac_of_measured_copy_peak_6290": round(ach / 6290.0, 5),
+            "whole_step": {"alg_bytes": int(bytes_step), "gpu_ms": round(ms_total, 4),
+                           "achieved_GBs": round(bytes_step / (ms_total * 1e-3) / 1e9, 2)},
+            "note": "algorithmic bytes are defined on the reference's unpruned traversal in the reference's record "
+                    "sizes (SURVEY.md 8d); the scene is L2/Infinity-Cache resident, so measured HBM traffic is far "
+                    "below them and frac can exceed 1 -- see DESIGN.md",
         }
         # ---- CPU baseline: the oracle (a port, not the reference binary) on a bounded sample
         if args.cpu_seconds > 0:

@@ -12,6 +12,7 @@
 
 #include "ezrt.h"
 #include "ezrt_kernels.h"
+#include "ezrt_wavefront.h"
 
 using namespace ezd;
 
@@ -75,6 +76,12 @@ struct EzrtScene {
   bool blocks_valid = false;
   DevBuf<float4> samples;
   DevBuf<float4> accum_tmp;
+  // wavefront queues (ping-pong)
+  DevBuf<float4> rq_o[2], rq_d[2];
+  DevBuf<float4> st[2][5];
+  DevBuf<int2> hits;
+  DevBuf<uint32_t> qcounts; // [0..63] path counts per stage, [64..127] trace queue heads
+  int num_cus = 0;
   // timing
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   hipEvent_t ev_trace[MAX_TRACE_EVENTS][2];
@@ -198,6 +205,147 @@ int ensure_events(EzrtScene* s) {
 size_t stack_lds_bytes(const EzrtScene* s) {
   int entries = s->depth > 1 ? s->depth : 1; // pending far children <= depth - 1
   return (size_t)entries * BLOCK * sizeof(int);
+}
+
+
+// ---- wavefront pipeline for one chunk of frames (all launches asynchronous on `st`)
+template <int INTEG>
+void launch_shade_i(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
+  if (full) hipLaunchKernelGGL((shade_kernel<INTEG, true>), grid, dim3(BLOCK), 0, st, a);
+  else hipLaunchKernelGGL((shade_kernel<INTEG, false>), grid, dim3(BLOCK), 0, st, a);
+}
+void launch_shade(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
+  switch (a.p.integrator) {
+    case EZRT_INTEGRATOR_P3_DIFFUSE: launch_shade_i<EZRT_INTEGRATOR_P3_DIFFUSE>(a, full, grid, st); break;
+    case EZRT_INTEGRATOR_P4_DISNEY: launch_shade_i<EZRT_INTEGRATOR_P4_DISNEY>(a, full, grid, st); break;
+    case EZRT_INTEGRATOR_P5_SOBOL: launch_shade_i<EZRT_INTEGRATOR_P5_SOBOL>(a, full, grid, st); break;
+    default: launch_shade_i<EZRT_INTEGRATOR_P5_MIS>(a, full, grid, st); break;
+  }
+}
+
+int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t frame_first, uint32_t nf, hipStream_t st) {
+  const bool mis = p->integrator == EZRT_INTEGRATOR_P5_MIS;
+  const bool full = s->instr > 0;
+  const size_t n_slots = (size_t)nb * BLOCK * nf;
+  const size_t n_rays_max = n_slots * (mis ? 2 : 1);
+  if (p->max_bounce + 2 > 64) return fail(EZRT_ERR_UNSUPPORTED, "max_bounce too large for the stage counters");
+  for (int k = 0; k < 2; k++) {
+    HIP_TRY(s->rq_o[k].ensure(n_rays_max));
+    HIP_TRY(s->rq_d[k].ensure(n_rays_max));
+    for (int j = 0; j < (mis ? 5 : 4); j++) HIP_TRY(s->st[k][j].ensure(n_slots));
+  }
+  HIP_TRY(s->hits.ensure(n_rays_max));
+  HIP_TRY(s->qcounts.ensure(128));
+  HIP_TRY(hipMemsetAsync(s->qcounts.p, 0, 128 * sizeof(uint32_t), st));
+  if (!s->num_cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    s->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  auto queue = [&](int k) {
+    RayQueue q;
+    q.o = s->rq_o[k].p;
+    q.d = s->rq_d[k].p;
+    return q;
+  };
+  auto state = [&](int k) {
+    PathState t;
+    t.s0 = s->st[k][0].p;
+    t.s1 = s->st[k][1].p;
+    t.s2 = s->st[k][2].p;
+    t.s3 = s->st[k][3].p;
+    t.s4 = s->st[k][4].p;
+    return t;
+  };
+  WfArgs a;
+  a.sc = s->dev();
+  a.p = *p;
+  a.blocks = s->blocks.p;
+  a.n_blocks = nb;
+  a.frame_first = frame_first;
+  a.n_slots = (uint32_t)n_slots;
+  a.samples = s->samples.p;
+  a.counters = s->counters.p;
+  a.hits = s->hits.p;
+  // raygen -> queue 0
+  a.rq_in = queue(1);
+  a.rq_out = queue(0);
+  a.st_in = state(1);
+  a.st_out = state(0);
+  a.n_in = s->qcounts.p;
+  a.n_out = s->qcounts.p;
+  a.bounce = 0;
+  hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((n_slots + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, a);
+
+  const size_t lds = stack_lds_bytes(s);
+  int blocks_per_cu = (int)((150 * 1024) / (lds ? lds : 1));
+  if (blocks_per_cu > 8) blocks_per_cu = 8;
+  if (blocks_per_cu < 1) blocks_per_cu = 1;
+  const unsigned trace_grid = (unsigned)(s->num_cus * blocks_per_cu);
+  unsigned shade_grid = (unsigned)((n_slots + BLOCK - 1) / BLOCK);
+  if (shade_grid > 8192u) shade_grid = 8192u;
+  static int trace_wps = -1;
+  if (trace_wps < 0) {
+    const char* e = getenv("EZRT_TRACE_WPS");
+    trace_wps = e ? atoi(e) : 6;
+  }
+  static int debug_stages = -1;
+  if (debug_stages < 0) {
+    const char* e = getenv("EZRT_DEBUG_STAGES");
+    debug_stages = (e && atoi(e) != 0) ? 1 : 0;
+  }
+  static int leaf_thr = -1;
+  if (leaf_thr < 0) {
+    const char* e = getenv("EZRT_LEAF_THRESHOLD");
+    leaf_thr = e ? atoi(e) : 24;
+  }
+
+  for (int b = 0; b <= p->max_bounce; b++) {
+    const int in = b & 1, out = in ^ 1;
+    TraceQArgs t;
+    t.sc = a.sc;
+    t.rq = queue(in);
+    t.hits = s->hits.p;
+    t.n_paths = s->qcounts.p + b;
+    t.rays_per_path = (mis && b > 0) ? 2u : 1u;
+    t.head = s->qcounts.p + 64 + b;
+    t.counters = s->counters.p;
+    t.leaf_threshold = leaf_thr;
+    t.dbg = debug_stages ? (s->qcounts.p + 100 + 4 * (b & 3)) : nullptr;
+    int e = s->n_trace_events;
+    if (e < MAX_TRACE_EVENTS) HIP_TRY(hipEventRecord(s->ev_trace[e][0], st));
+    if (full) hipLaunchKernelGGL((traceq_kernel<true, 6>), dim3(trace_grid), dim3(BLOCK), lds, st, t);
+    else if (trace_wps == 8) hipLaunchKernelGGL((traceq_kernel<false, 8>), dim3(trace_grid), dim3(BLOCK), lds, st, t);
+    else hipLaunchKernelGGL((traceq_kernel<false, 6>), dim3(trace_grid), dim3(BLOCK), lds, st, t);
+    if (e < MAX_TRACE_EVENTS) {
+      HIP_TRY(hipEventRecord(s->ev_trace[e][1], st));
+      s->n_trace_events++;
+    }
+    s->n_trace_launches++;
+    a.rq_in = queue(in);
+    a.rq_out = queue(out);
+    a.st_in = state(in);
+    a.st_out = state(out);
+    a.n_in = s->qcounts.p + b;
+    a.n_out = s->qcounts.p + b + 1;
+    a.bounce = b;
+    launch_shade(a, full, dim3(shade_grid), st);
+    if (debug_stages) { // diagnostic only: per-stage queue sizes and counters (synchronises)
+      uint32_t q[2] = {0, 0};
+      unsigned long long c[EZRT_CTR_COUNT];
+      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(hipMemcpy(q, s->qcounts.p + b, sizeof q, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(c, s->counters.p, sizeof c, hipMemcpyDeviceToHost));
+      uint32_t dbg[3] = {0, 0, 0};
+      HIP_TRY(hipMemcpy(dbg, s->qcounts.p + 100 + 4 * (b & 3), sizeof dbg, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemset(s->qcounts.p + 100 + 4 * (b & 3), 0, sizeof dbg));
+      fprintf(stderr, "[ezrt] stage %d: paths_in %u paths_out %u | cum rays %llu pops %llu inner %llu tris %llu | max/ray pops %u tris %u iters %u\n", b, q[0],
+              q[1], c[0], c[1], c[2], c[3], dbg[0], dbg[1], dbg[2]);
+    }
+  }
+  return 0;
 }
 
 } // namespace
@@ -365,35 +513,45 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
   const int nb = (int)s->blocks_host.size();
   HIP_TRY(hipEventRecord(s->ev_begin, st));
   if (nb > 0 && p->spp > 0) {
-    // frames per launch: bound the sample buffer to ~512 MiB
+    // frames per chunk: at most 2^24 pixel-samples in flight (sample buffer 256 MiB + queues)
     const size_t per_frame = (size_t)nb * BLOCK;
-    size_t chunk = (size_t)(32u << 20) / per_frame;
+    size_t chunk = (size_t)(16u << 20) / per_frame;
     if (chunk < 1) chunk = 1;
     if (chunk > p->spp) chunk = p->spp;
     HIP_TRY(s->samples.ensure(per_frame * chunk));
+    static int use_mega = -1;
+    if (use_mega < 0) {
+      const char* e = getenv("EZRT_MEGAKERNEL");
+      use_mega = (e && atoi(e) != 0) ? 1 : 0;
+    }
     const size_t lds = stack_lds_bytes(s);
     for (uint32_t done = 0; done < p->spp;) {
       uint32_t nf = (uint32_t)((p->spp - done < chunk) ? (p->spp - done) : chunk);
-      TraceArgs a;
-      a.sc = s->dev();
-      a.p = *p;
-      a.blocks = s->blocks.p;
-      a.n_blocks = nb;
-      a.frame_first = p->frame0 + done;
-      a.samples = s->samples.p;
-      a.counters = s->counters.p;
-      a.log_tri = nullptr;
-      a.log_t = nullptr;
-      a.log_colour = nullptr;
-      a.stack_entries = s->depth;
-      int e = s->n_trace_events;
-      if (e < MAX_TRACE_EVENTS) HIP_TRY(hipEventRecord(s->ev_trace[e][0], st));
-      launch_trace(a, s->instr > 0 ? 1 : 0, dim3((unsigned)((size_t)nb * nf)), lds, st);
-      if (e < MAX_TRACE_EVENTS) {
-        HIP_TRY(hipEventRecord(s->ev_trace[e][1], st));
-        s->n_trace_events++;
+      if (use_mega) {
+        TraceArgs a;
+        a.sc = s->dev();
+        a.p = *p;
+        a.blocks = s->blocks.p;
+        a.n_blocks = nb;
+        a.frame_first = p->frame0 + done;
+        a.samples = s->samples.p;
+        a.counters = s->counters.p;
+        a.log_tri = nullptr;
+        a.log_t = nullptr;
+        a.log_colour = nullptr;
+        a.stack_entries = s->depth;
+        int e = s->n_trace_events;
+        if (e < MAX_TRACE_EVENTS) HIP_TRY(hipEventRecord(s->ev_trace[e][0], st));
+        launch_trace(a, s->instr > 0 ? 1 : 0, dim3((unsigned)((size_t)nb * nf)), lds, st);
+        if (e < MAX_TRACE_EVENTS) {
+          HIP_TRY(hipEventRecord(s->ev_trace[e][1], st));
+          s->n_trace_events++;
+        }
+        s->n_trace_launches++;
+      } else {
+        rc = wavefront_chunk(s, p, nb, p->frame0 + done, nf, st);
+        if (rc) return rc;
       }
-      s->n_trace_launches++;
       AccumArgs b;
       b.p = *p;
       b.blocks = s->blocks.p;
