@@ -112,6 +112,25 @@ EZD float hit_aabb(f3 S, f3 inv, f3 AA, f3 BB) {
   return (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
 }
 
+// Same slab test on v_min_f32 / v_max_f32 / v_min3 / v_max3 (one issue slot each instead of
+// compare + hazard nop + select).  Hardware min/max differ from (b<a)?b:a only on NaN operands and on
+// the sign of a zero result; the result is consumed by comparisons only (sign of zero is invisible) and
+// no NaN can arise when the ray's origin and 1/direction are finite (finite box minus finite origin
+// times a finite factor is finite or +-inf, never NaN).  Callers use it only for such rays
+// (ray_is_tame) and fall back to hit_aabb otherwise, so decisions stay bit-identical.
+EZD float hit_aabb_tame(f3 S, f3 inv, f3 AA, f3 BB) {
+  f3 f = (BB - S) * inv;
+  f3 n = (AA - S) * inv;
+  float t1 = __builtin_fminf(__builtin_fmaxf(f.x, n.x), __builtin_fminf(__builtin_fmaxf(f.y, n.y), __builtin_fmaxf(f.z, n.z)));
+  float t0 = __builtin_fmaxf(__builtin_fminf(f.x, n.x), __builtin_fmaxf(__builtin_fminf(f.y, n.y), __builtin_fminf(f.z, n.z)));
+  return (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
+}
+EZD bool ray_is_tame(f3 S, f3 inv) {
+  const float big = 3.0e38f;
+  return ez_abs(S.x) < big && ez_abs(S.y) < big && ez_abs(S.z) < big && ez_abs(inv.x) < big && ez_abs(inv.y) < big &&
+         ez_abs(inv.z) < big;
+}
+
 // hitTriangle, distance part: P5/fsh:160-198.  Flipping N (fsh:175-178) negates
 // numerator, denominator and all three edge signs exactly, so t and the hit
 // decision do not depend on it; isInside is recomputed for the winner.
@@ -225,8 +244,10 @@ EZD void shade_point(const DevScene& sc, int32_t tri, float t, f3 S, f3 d, Hit& 
   f3 N = mk(a.w, b.w, c.w);
   bool inside = dot(N, d) > 0.0f;
   f3 P = S + d * t;
-  const float* r = sc.tri_ref + (size_t)tri * 36;
-  f3 n1 = ld3(r + 9), n2 = ld3(r + 12), n3 = ld3(r + 15);
+  // texels 3-11 of the reference record (floats 9..35) as seven aligned 16-B loads
+  const float4* rq = reinterpret_cast<const float4*>(sc.tri_ref + (size_t)tri * 36);
+  const float4 r2 = rq[2], r3 = rq[3], r4 = rq[4], r5 = rq[5], r6 = rq[6], r7 = rq[7], r8 = rq[8];
+  f3 n1 = mk(r2.y, r2.z, r2.w), n2 = mk(r3.x, r3.y, r3.z), n3 = mk(r3.w, r4.x, r4.y);
   float alpha, beta;
   if (P5TRI) { // P5/fsh:206-207
     alpha = (-(P.x - p2.x) * (p3.y - p2.y) + (P.y - p2.y) * (p3.x - p2.x)) /
@@ -244,18 +265,18 @@ EZD void shade_point(const DevScene& sc, int32_t tri, float t, f3 S, f3 d, Hit& 
   h.P = P;
   h.N = inside ? -Ns : Ns;
   h.viewDir = d;
-  h.m.emissive = ld3(r + 18);
-  h.m.baseColor = ld3(r + 21);
-  h.m.subsurface = r[24];
-  h.m.metallic = r[25];
-  h.m.specular = r[26];
-  h.m.specularTint = r[27];
-  h.m.roughness = r[28];
-  h.m.anisotropic = r[29];
-  h.m.sheen = r[30];
-  h.m.sheenTint = r[31];
-  h.m.clearcoat = r[32];
-  h.m.clearcoatGloss = r[33];
+  h.m.emissive = mk(r4.z, r4.w, r5.x);
+  h.m.baseColor = mk(r5.y, r5.z, r5.w);
+  h.m.subsurface = r6.x;
+  h.m.metallic = r6.y;
+  h.m.specular = r6.z;
+  h.m.specularTint = r6.w;
+  h.m.roughness = r7.x;
+  h.m.anisotropic = r7.y;
+  h.m.sheen = r7.z;
+  h.m.sheenTint = r7.w;
+  h.m.clearcoat = r8.x;
+  h.m.clearcoatGloss = r8.y;
 }
 
 // ---------------------------------------------------------------------------

@@ -211,8 +211,8 @@ size_t stack_lds_bytes(const EzrtScene* s) {
 // ---- wavefront pipeline for one chunk of frames (all launches asynchronous on `st`)
 template <int INTEG>
 void launch_shade_i(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
-  if (full) hipLaunchKernelGGL((shade_kernel<INTEG, true>), grid, dim3(BLOCK), 0, st, a);
-  else hipLaunchKernelGGL((shade_kernel<INTEG, false>), grid, dim3(BLOCK), 0, st, a);
+  if (full) hipLaunchKernelGGL((shade_kernel<INTEG, true>), grid, dim3(SHADE_BLOCK), 0, st, a);
+  else hipLaunchKernelGGL((shade_kernel<INTEG, false>), grid, dim3(SHADE_BLOCK), 0, st, a);
 }
 void launch_shade(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
   switch (a.p.integrator) {
@@ -284,22 +284,29 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
   if (blocks_per_cu > 8) blocks_per_cu = 8;
   if (blocks_per_cu < 1) blocks_per_cu = 1;
   const unsigned trace_grid = (unsigned)(s->num_cus * blocks_per_cu);
-  unsigned shade_grid = (unsigned)((n_slots + BLOCK - 1) / BLOCK);
-  if (shade_grid > 8192u) shade_grid = 8192u;
+  unsigned shade_grid = (unsigned)((n_slots + SHADE_BLOCK - 1) / SHADE_BLOCK);
+  if (shade_grid > 2048u) shade_grid = 2048u;
   static int trace_wps = -1;
   if (trace_wps < 0) {
     const char* e = getenv("EZRT_TRACE_WPS");
-    trace_wps = e ? atoi(e) : 6;
+    trace_wps = e ? atoi(e) : 5;
   }
   static int debug_stages = -1;
   if (debug_stages < 0) {
     const char* e = getenv("EZRT_DEBUG_STAGES");
     debug_stages = (e && atoi(e) != 0) ? 1 : 0;
   }
+  static int pool_div = -1, pool_max = -1;
+  if (pool_div < 0) {
+    const char* e = getenv("EZRT_POOL_DIV");
+    pool_div = e ? atoi(e) : 1;
+    e = getenv("EZRT_POOL_MAX");
+    pool_max = e ? atoi(e) : 256;
+  }
   static int leaf_thr = -1;
   if (leaf_thr < 0) {
     const char* e = getenv("EZRT_LEAF_THRESHOLD");
-    leaf_thr = e ? atoi(e) : 24;
+    leaf_thr = e ? atoi(e) : 4;
   }
 
   for (int b = 0; b <= p->max_bounce; b++) {
@@ -313,12 +320,18 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
     t.head = s->qcounts.p + 64 + b;
     t.counters = s->counters.p;
     t.leaf_threshold = leaf_thr;
+    t.pool_div = (uint32_t)pool_div;
+    t.pool_max = (uint32_t)pool_max;
+    t.stack_entries = (int32_t)(lds / (BLOCK * sizeof(int)));
     t.dbg = debug_stages ? (s->qcounts.p + 100 + 4 * (b & 3)) : nullptr;
     int e = s->n_trace_events;
     if (e < MAX_TRACE_EVENTS) HIP_TRY(hipEventRecord(s->ev_trace[e][0], st));
-    if (full) hipLaunchKernelGGL((traceq_kernel<true, 6>), dim3(trace_grid), dim3(BLOCK), lds, st, t);
-    else if (trace_wps == 8) hipLaunchKernelGGL((traceq_kernel<false, 8>), dim3(trace_grid), dim3(BLOCK), lds, st, t);
-    else hipLaunchKernelGGL((traceq_kernel<false, 6>), dim3(trace_grid), dim3(BLOCK), lds, st, t);
+    const size_t lds_t = lds + (BLOCK / 64) * 64 * sizeof(int); // + per-wave lane table of the cooperative leaf phase
+    if (full) hipLaunchKernelGGL((traceq_kernel<true, 6>), dim3(trace_grid), dim3(BLOCK), lds_t, st, t);
+    else if (trace_wps == 8) hipLaunchKernelGGL((traceq_kernel<false, 8>), dim3(trace_grid), dim3(BLOCK), lds_t, st, t);
+    else if (trace_wps == 5) hipLaunchKernelGGL((traceq_kernel<false, 5>), dim3(trace_grid), dim3(BLOCK), lds_t, st, t);
+    else if (trace_wps == 4) hipLaunchKernelGGL((traceq_kernel<false, 4>), dim3(trace_grid), dim3(BLOCK), lds_t, st, t);
+    else hipLaunchKernelGGL((traceq_kernel<false, 6>), dim3(trace_grid), dim3(BLOCK), lds_t, st, t);
     if (e < MAX_TRACE_EVENTS) {
       HIP_TRY(hipEventRecord(s->ev_trace[e][1], st));
       s->n_trace_events++;

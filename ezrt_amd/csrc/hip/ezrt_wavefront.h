@@ -28,7 +28,7 @@ namespace ezd {
 constexpr uint32_t FLAG_SHADOW_SHOT = 1u;  // slot 2i holds a live env shadow ray
 constexpr uint32_t FLAG_TERMINATE = 2u;    // NdotL <= 0 (P5/fsh:854): finish after the shadow result
 constexpr uint32_t FLAG_PDF_DEAD = 4u;     // pdf_brdf <= 0 (P5/fsh:865): ray shot, then break
-constexpr uint32_t TRACE_POOL_MAX = 128;   // ray indices a wave reserves per atomic (large queues)
+constexpr uint32_t TRACE_POOL_MAX = 2048;  // ray indices a wave reserves per atomic (large queues)
 constexpr uint32_t TRACE_POOL_MIN = 8;     // ... small queues are spread over every resident wave
 
 struct PathState { // SoA of float4, one slot per live path
@@ -113,6 +113,8 @@ struct TraceQArgs {
   uint32_t* head;          // queue head (device, zeroed per launch)
   unsigned long long* counters;
   int32_t leaf_threshold;  // lanes waiting at a leaf that trigger the triangle phase
+  uint32_t pool_div, pool_max; // pool = clamp(n_rays / (n_waves * pool_div), 8, pool_max)
+  int32_t stack_entries;   // LDS stack rows (tree depth); the per-wave lane table follows them
   uint32_t* dbg;           // diagnostic (FULLCTR only): [0] max pops/ray [1] max tris/ray [2] max loop iterations/ray
 };
 
@@ -130,8 +132,10 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
   // reservation size: a short queue (late bounces: few, deep rays) is dealt out in small pools so
   // that every resident wave gets a few lanes of work instead of a few waves getting all of it
   const uint32_t n_waves = gridDim.x * (BLOCK / 64);
-  uint32_t pool_size = n_rays / n_waves;
-  pool_size = pool_size > TRACE_POOL_MAX ? TRACE_POOL_MAX : (pool_size < TRACE_POOL_MIN ? TRACE_POOL_MIN : pool_size);
+  // (one queue-head word sustains only ~88 atomics/us chip-wide -- MI355X_MICROARCH.md "dequeue" --
+  // so a wave takes ~1/4 of its fair share per atomic: <= ~4 atomics per wave per launch)
+  uint32_t pool_size = n_rays / (n_waves * a.pool_div);
+  pool_size = pool_size > a.pool_max ? a.pool_max : (pool_size < TRACE_POOL_MIN ? TRACE_POOL_MIN : pool_size);
 
   // wave-uniform pool of reserved ray indices
   uint32_t pool_next = 0, pool_end = 0;
@@ -144,6 +148,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
 
   // current ray
   bool work = false;
+  bool wild = false; // current ray needs the exact NaN-aware slab test
   uint32_t slot = 0;
   f3 S = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
   float best_t = INF;
@@ -167,6 +172,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
           S = mk(nx_o.x, nx_o.y, nx_o.z);
           d = mk(nx_d.x, nx_d.y, nx_d.z);
           inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+          wild = !ray_is_tame(S, inv);
           best_t = INF;
           best_tri = -1;
           sp = 0;
@@ -226,8 +232,14 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
       if (FULLCTR) ctr.inner++;
       const float4* r = sc.inner + (size_t)ref * 4;
       float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
-      float d1 = hit_aabb(S, inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));
-      float d2 = hit_aabb(S, inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w));
+      float d1, d2;
+      if (__ballot(wild)) { // some lane's ray has a zero/NaN direction component: exact select-based min/max
+        d1 = hit_aabb(S, inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));
+        d2 = hit_aabb(S, inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w));
+      } else {
+        d1 = hit_aabb_tame(S, inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));
+        d2 = hit_aabb_tame(S, inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w));
+      }
       uint32_t left = __float_as_uint(q3.x), right = __float_as_uint(q3.y);
       bool h1 = d1 > 0.0f, h2 = d2 > 0.0f;
       if (h1 && h2) {
@@ -256,7 +268,51 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
     if (lm) {
       bool go = (int)__popcll(lm) >= a.leaf_threshold || !__ballot(work && !(ref & LEAF_BIT));
       if (go) {
-        if (at_leaf) {
+        const int Lc = (int)__popcll(lm);
+        if (!FULLCTR && Lc <= 32) {
+          // Cooperative leaf phase: the Lc waiting rays share the whole wave.  g = 64 / Lc lanes
+          // (power of two) work for each ray, lane m of a group testing triangles m, m+g, ... of
+          // that ray's leaf, so a leaf of <= g triangles costs ONE dependent round instead of n.
+          // The group minimum of (t bits << 32 | triangle index) is the first triangle (in leaf
+          // order) with the smallest t -- exactly hitArray's strict-< scan (P5/fsh:242-249).
+          const int sh = (Lc <= 1) ? 0 : (32 - __clz(Lc - 1));
+          const int g = 64 >> sh;
+          int* wsrc = lds_stack + a.stack_entries * BLOCK + (threadIdx.x >> 6) * 64;
+          const uint32_t rank = lane_rank(lm);
+          if (at_leaf) wsrc[rank] = lane;
+          __builtin_amdgcn_wave_barrier();
+          const int grp = lane >> (6 - sh), m = lane & (g - 1);
+          const bool helper = grp < Lc;
+          const int src = helper ? wsrc[grp] : lane;
+          const float sx = __shfl(S.x, src, 64), sy = __shfl(S.y, src, 64), sz = __shfl(S.z, src, 64);
+          const float dx = __shfl(d.x, src, 64), dy = __shfl(d.y, src, 64), dz = __shfl(d.z, src, 64);
+          const uint32_t lref = (uint32_t)__shfl((int)ref, src, 64);
+          unsigned long long key = ~0ull;
+          if (helper) {
+            const int first = (int)(lref & 0x00ffffffu);
+            const int n = (int)((lref >> 24) & 0x7fu) + 1;
+            for (int k = m; k < n; k += g) {
+              float t;
+              bool hit = hit_triangle_t(sc.tri_geom + (size_t)(first + k) * 3, mk(sx, sy, sz), mk(dx, dy, dz), t);
+              if (hit) {
+                unsigned long long k2 = ((unsigned long long)__float_as_uint(t) << 32) | (uint32_t)(first + k);
+                key = k2 < key ? k2 : key;
+              }
+            }
+          }
+          for (int off = 1; off < g; off <<= 1) {
+            unsigned long long other = __shfl_xor(key, off, 64);
+            key = other < key ? other : key;
+          }
+          const unsigned long long mine = __shfl(key, (int)(rank << (6 - sh)), 64);
+          if (at_leaf && mine != ~0ull) {
+            float t = __uint_as_float((uint32_t)(mine >> 32));
+            if (t < best_t) {
+              best_t = t;
+              best_tri = (int32_t)(uint32_t)mine;
+            }
+          }
+        } else if (at_leaf) {
           int first = (int)(ref & 0x00ffffffu);
           int n = (int)((ref >> 24) & 0x7fu) + 1;
           if (FULLCTR) leaf_best = INF;
@@ -275,6 +331,8 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
               best_tri = i;
             }
           }
+        }
+        if (at_leaf) {
           if (sp > 0) {
             sp--;
             ref = (uint32_t)stack[sp * BLOCK];
@@ -304,6 +362,31 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
 
 // ---------------------------------------------------------------------------
 // shading stage
+constexpr int SHADE_BLOCK = 1024; // 16 waves share ONE queue-tail atomic per iteration (see block_alloc)
+
+// Compaction slot for every lane with `want`: wave ballots -> per-wave counts in LDS -> one
+// atomicAdd per 1024-thread workgroup -> wave offsets.  A single queue-tail word only sustains
+// ~88 atomics/us, so per-wave atomics (118 k per stage on C2) would cost more than the shading.
+EZD uint32_t block_alloc(uint32_t* counter, bool want, uint32_t* lds /* [SHADE_BLOCK/64 + 1] */) {
+  const unsigned long long m = __ballot(want);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int NW = SHADE_BLOCK / 64;
+  __syncthreads(); // previous iteration's readers are done with lds
+  if (lane == 0) lds[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+    for (int w = 0; w < NW; w++) {
+      uint32_t c = lds[w];
+      lds[w] = total;
+      total += c;
+    }
+    lds[NW] = total ? atomicAdd(counter, total) : 0u;
+  }
+  __syncthreads();
+  return lds[NW] + lds[wave] + lane_rank(m);
+}
+
 EZD uint32_t wave_alloc(uint32_t* counter, bool want) {
   unsigned long long m = __ballot(want);
   if (!m) return 0;
@@ -315,19 +398,20 @@ EZD uint32_t wave_alloc(uint32_t* counter, bool want) {
 }
 
 template <int INTEG, bool FULLCTR>
-__global__ __launch_bounds__(BLOCK) void shade_kernel(WfArgs a) {
+__global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(WfArgs a) {
+  __shared__ uint32_t alloc_lds[SHADE_BLOCK / 64 + 1];
   constexpr bool P5TRI = (INTEG >= 50);
   constexpr bool MIS = (INTEG == EZRT_INTEGRATOR_P5_MIS);
   const DevScene& sc = a.sc;
   const EzrtRenderParams& p = a.p;
   const int b = a.bounce;
   const uint32_t n_in = (b == 0) ? a.n_slots : *a.n_in;
-  const uint32_t stride = gridDim.x * BLOCK;
+  const uint32_t stride = gridDim.x * SHADE_BLOCK;
   const uint32_t n_round = (n_in + stride - 1) / stride * stride; // keep waves whole for the ballots
   Counters ctr = {0, 0, 0, 0, 0, 0, 0};
   uint32_t n_samples = 0;
 
-  for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += stride) {
+  for (uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x; i < n_round; i += stride) {
     bool live = i < n_in;       // this lane holds a path
     bool emit = false;          // ... that continues into the next queue
     uint32_t sslot = 0, seed = 0, flags = 0;
@@ -337,31 +421,45 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(WfArgs a) {
     Hit hit;
     hit.P = mk(0, 0, 0);
 
+    // first-level loads: addresses depend on i only, so issue them all up front (one memory
+    // round trip) instead of discovering them one branch at a time
+    const uint32_t ii = live ? i : 0u;
+    const uint32_t rslot = (b == 0 || !MIS) ? ii : (2u * ii + 1u);
+    const float4 rd4 = a.rq_in.d[rslot];
+    const float4 ro4 = a.rq_in.o[rslot];
+    const int2 h = a.hits[rslot];
+    const float4 s3 = a.st_in.s3[ii];
+    float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, s4 = s0;
+    int2 sh = make_int2(-1, 0);
+    if (b > 0) {
+      s0 = a.st_in.s0[ii];
+      s1 = a.st_in.s1[ii];
+      s2 = a.st_in.s2[ii];
+      if (MIS) {
+        s4 = a.st_in.s4[ii];
+        sh = a.hits[2u * ii];
+      }
+    }
+    bool done = false;
     if (live) {
-      const uint32_t rslot = (b == 0 || !MIS) ? i : (2u * i + 1u);
-      const float4 rd4 = a.rq_in.d[rslot];
-      bool done = false;
       f3 colour = mk(0, 0, 0);
+      const f3 rd = mk(rd4.x, rd4.y, rd4.z);
       if (b == 0) {
         sslot = i;
         if (rd4.w == 0.0f) {
           live = false; // pixel not owned by this shard
         } else {
           n_samples = n_samples + 1;
-          const float4 ro4 = a.rq_in.o[rslot];
-          const int2 h = a.hits[rslot];
-          const f3 rd = mk(rd4.x, rd4.y, rd4.z);
           if (h.x < 0) { // primary miss: P5/fsh:931-933
             colour = hdr_color<FULLCTR>(sc, rd, p.env_clamp, ctr);
             done = true;
           } else {
             shade_point<P5TRI>(sc, h.x, __int_as_float(h.y), mk(ro4.x, ro4.y, ro4.z), rd, hit);
             Le0 = hit.m.emissive;
-            seed = __float_as_uint(a.st_in.s3[i].w);
+            seed = __float_as_uint(s3.w);
           }
         }
       } else {
-        const float4 s0 = a.st_in.s0[i], s1 = a.st_in.s1[i], s2 = a.st_in.s2[i], s3 = a.st_in.s3[i];
         history = mk(s0.x, s0.y, s0.z);
         cosine = s0.w;
         Lo = mk(s1.x, s1.y, s1.z);
@@ -371,10 +469,8 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(WfArgs a) {
         Le0 = mk(s3.x, s3.y, s3.z);
         seed = __float_as_uint(s3.w);
         if (MIS) {
-          const float4 s4 = a.st_in.s4[i];
           flags = __float_as_uint(s4.w);
           if (flags & FLAG_SHADOW_SHOT) { // P5/fsh:826-841
-            const int2 sh = a.hits[2u * i];
             if (sh.x < 0) {
               Lo = Lo + mk(s4.x, s4.y, s4.z);
               if (FULLCTR) {
@@ -389,9 +485,6 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(WfArgs a) {
         } else if (MIS && (flags & FLAG_PDF_DEAD)) {
           done = true;
         } else {
-          const float4 ro4 = a.rq_in.o[rslot];
-          const int2 h = a.hits[rslot];
-          const f3 rd = mk(rd4.x, rd4.y, rd4.z);
           if (h.x < 0) {
             f3 sky = hdr_color<FULLCTR>(sc, rd, p.env_clamp, ctr);
             if (MIS) {
@@ -488,7 +581,7 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(WfArgs a) {
     }
 
     // ---- compaction: one ballot + one atomic per wave
-    const uint32_t o = wave_alloc(a.n_out, emit);
+    const uint32_t o = block_alloc(a.n_out, emit, alloc_lds);
     if (emit) {
       a.st_out.s0[o] = make_float4(history.x, history.y, history.z, cosine);
       a.st_out.s1[o] = make_float4(Lo.x, Lo.y, Lo.z, pdf);
