@@ -82,6 +82,7 @@ struct EzrtScene {
   DevBuf<int2> hits;
   DevBuf<uint32_t> qcounts; // [0..63] path counts per stage, [64..127] trace queue heads
   int num_cus = 0;
+  int n_inner = 0;
   // timing
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   hipEvent_t ev_trace[MAX_TRACE_EVENTS][2];
@@ -280,17 +281,32 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
   hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((n_slots + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, a);
 
   const size_t lds = stack_lds_bytes(s);
-  int blocks_per_cu = (int)((150 * 1024) / (lds ? lds : 1));
-  if (blocks_per_cu > 8) blocks_per_cu = 8;
-  if (blocks_per_cu < 1) blocks_per_cu = 1;
-  const unsigned trace_grid = (unsigned)(s->num_cus * blocks_per_cu);
-  unsigned shade_grid = (unsigned)((n_slots + SHADE_BLOCK - 1) / SHADE_BLOCK);
-  if (shade_grid > 2048u) shade_grid = 2048u;
   static int trace_wps = -1;
   if (trace_wps < 0) {
     const char* e = getenv("EZRT_TRACE_WPS");
     trace_wps = e ? atoi(e) : 5;
   }
+  static int lds_nodes_max = -1;
+  if (lds_nodes_max < 0) {
+    const char* e = getenv("EZRT_LDS_NODES");
+    lds_nodes_max = e ? atoi(e) : 1 << 20;
+  }
+  // LDS per workgroup: traversal stack + lane table + as many top-of-tree records (80 B each) as fit
+  // when the register budget's `trace_wps` waves/SIMD (= trace_wps workgroups of 256 per CU) are resident
+  const size_t lds_fixed = lds + BLOCK * sizeof(int);
+  int blocks_per_cu = trace_wps > 0 ? trace_wps : 5;
+  if ((size_t)blocks_per_cu * lds_fixed > 158 * 1024) blocks_per_cu = (int)((158 * 1024) / lds_fixed);
+  if (blocks_per_cu < 1) blocks_per_cu = 1;
+  size_t lds_budget = (size_t)(158 * 1024) / blocks_per_cu;
+  if (lds_budget > 64 * 1024) lds_budget = 64 * 1024;
+  lds_budget -= lds_budget / 16; // allocation-granule slack: a workgroup must not lose its CU slot to rounding // static cap of a dynamic-LDS launch without opt-in
+  int lds_nodes = lds_budget > lds_fixed ? (int)((lds_budget - lds_fixed) / 80) : 0;
+  if (lds_nodes > s->n_inner) lds_nodes = s->n_inner;
+  if (lds_nodes > lds_nodes_max) lds_nodes = lds_nodes_max;
+  const size_t lds_t = lds_fixed + (size_t)lds_nodes * 80;
+  const unsigned trace_grid = (unsigned)(s->num_cus * blocks_per_cu);
+  unsigned shade_grid = (unsigned)((n_slots + SHADE_BLOCK - 1) / SHADE_BLOCK);
+  if (shade_grid > 2048u) shade_grid = 2048u;
   static int debug_stages = -1;
   if (debug_stages < 0) {
     const char* e = getenv("EZRT_DEBUG_STAGES");
@@ -323,10 +339,10 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
     t.pool_div = (uint32_t)pool_div;
     t.pool_max = (uint32_t)pool_max;
     t.stack_entries = (int32_t)(lds / (BLOCK * sizeof(int)));
+    t.lds_nodes = lds_nodes;
     t.dbg = debug_stages ? (s->qcounts.p + 100 + 4 * (b & 3)) : nullptr;
     int e = s->n_trace_events;
     if (e < MAX_TRACE_EVENTS) HIP_TRY(hipEventRecord(s->ev_trace[e][0], st));
-    const size_t lds_t = lds + (BLOCK / 64) * 64 * sizeof(int); // + per-wave lane table of the cooperative leaf phase
     if (full) hipLaunchKernelGGL((traceq_kernel<true, 6>), dim3(trace_grid), dim3(BLOCK), lds_t, st, t);
     else if (trace_wps == 8) hipLaunchKernelGGL((traceq_kernel<false, 8>), dim3(trace_grid), dim3(BLOCK), lds_t, st, t);
     else if (trace_wps == 5) hipLaunchKernelGGL((traceq_kernel<false, 5>), dim3(trace_grid), dim3(BLOCK), lds_t, st, t);
@@ -409,7 +425,30 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
   if ((size_t)maxd * BLOCK * sizeof(int) > 150 * 1024)
     return fail(EZRT_ERR_UNSUPPORTED, "tree depth %d needs more LDS stack than one CU has", maxd);
 
-  // ---- device layout
+  // ---- device layout.  Inner records are numbered breadth-first from the root (ids are internal
+  // to the device layout) so that records [0, K) are the top levels of the tree: traceq_kernel stages
+  // that prefix in LDS.  Unreachable inner nodes (never visited) go last.
+  {
+    std::vector<int> order;
+    order.reserve((size_t)n_inner);
+    std::vector<char> seen((size_t)n_nodes, 0);
+    if (inner_id[1] >= 0) {
+      order.push_back(1);
+      seen[1] = 1;
+    }
+    for (size_t q = 0; q < order.size(); q++) {
+      HostNode h = decode_node(nodes, order[q]);
+      const int kids[2] = {h.left, h.right};
+      for (int c : kids)
+        if (inner_id[(size_t)c] >= 0 && !seen[(size_t)c]) {
+          seen[(size_t)c] = 1;
+          order.push_back(c);
+        }
+    }
+    for (int i = 1; i < n_nodes; i++)
+      if (inner_id[(size_t)i] >= 0 && !seen[(size_t)i]) order.push_back(i);
+    for (size_t q = 0; q < order.size(); q++) inner_id[(size_t)order[q]] = (int)q;
+  }
   auto ref_of = [&](int node) -> uint32_t {
     HostNode h = decode_node(nodes, node);
     if (h.n > 0) return LEAF_BIT | ((uint32_t)(h.n - 1) << 24) | (uint32_t)h.index;
@@ -448,6 +487,7 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
   s->n_tri = n_tri;
   s->n_nodes = n_nodes;
   s->depth = maxd;
+  s->n_inner = n_inner;
   s->root_ref = ref_of(1);
 #define SC_TRY(expr)                                                                              \
   do {                                                                                            \

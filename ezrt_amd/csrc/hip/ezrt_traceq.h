@@ -1,0 +1,298 @@
+// ezrt_traceq.h -- traceq_kernel: persistent hitBVH over a ray queue (the dominant kernel).
+//
+// Semantics per ray = hitBVH + hitArray + hitTriangle + hitAABB of the reference
+// (P5/fsh:160-306): unpruned, near child first, ties right-first, strict < keeps the first-found
+// hit.  Only the *schedule* is MI355X-specific:
+//
+//  * persistent workgroups; each lane owns one ray at a time and keeps its NEXT ray prefetched in
+//    registers, so a lane that finishes refills without a memory round trip and a wave never
+//    idles behind its slowest ray.  Waves reserve queue indices in pools (one atomic per pool);
+//  * the breadth-first top of the tree is staged in LDS once per workgroup (80-B stride, explicit
+//    LDS address space so the compiler emits ds_read_b128, not flat loads);
+//  * per-lane traversal stack in LDS, stack[row][256]: bank = lane % 32, conflict-free;
+//  * leaves are postponed until >= leaf_threshold lanes wait at one (ballot) or nobody can step;
+//    then the waiting rays share the WHOLE wave: g = 64 / Lc lanes per ray test triangles m, m+g,
+//    .. and a 64-bit (t bits, index) minimum across the group reproduces hitArray's first-minimum;
+//  * slab tests use v_min/v_max/v_min3/v_max3 for rays whose origin and 1/direction are finite
+//    (no NaN can arise; see hit_aabb_tame), the exact select form otherwise.
+#pragma once
+#include "ezrt_kernels.h"
+
+namespace ezd {
+
+constexpr uint32_t TRACE_POOL_MIN = 8; // smallest reservation: short queues are spread over every wave
+
+struct RayQueue {
+  float4* o; // origin.xyz, -
+  float4* d; // dir.xyz, valid (1) / skip (0)
+};
+
+struct TraceQArgs {
+  DevScene sc;
+  RayQueue rq;
+  int2* hits;
+  const uint32_t* n_paths; // device count; rays = n_paths * rays_per_path
+  uint32_t rays_per_path;
+  uint32_t* head;          // queue head (device, zeroed per launch)
+  unsigned long long* counters;
+  int32_t leaf_threshold;  // lanes waiting at a leaf that trigger the triangle phase
+  uint32_t pool_div, pool_max; // pool = clamp(n_rays / (n_waves * pool_div), 8, pool_max)
+  int32_t lds_nodes;       // inner records [0, lds_nodes) staged in LDS (after stack + lane table)
+  int32_t stack_entries;   // LDS stack rows (tree depth); the per-wave lane table follows them
+  uint32_t* dbg;           // diagnostic (FULLCTR only): [0] max pops/ray [1] max tris/ray [2] max iterations/ray
+};
+
+EZD uint32_t lane_rank(unsigned long long mask) { // number of set bits below this lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+template <bool FULLCTR, int WPS>
+__global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int lds_stack[];
+  int* stack = lds_stack + threadIdx.x;
+  const DevScene& sc = a.sc;
+  const uint32_t n_rays = (*a.n_paths) * a.rays_per_path;
+  const int lane = threadIdx.x & 63;
+  int* wsrc = lds_stack + a.stack_entries * BLOCK + (threadIdx.x >> 6) * 64;
+  float4* lds_nodes = reinterpret_cast<float4*>(lds_stack + a.stack_entries * BLOCK + BLOCK);
+  for (int k = threadIdx.x; k < a.lds_nodes * 4; k += BLOCK) lds_nodes[(k >> 2) * 5 + (k & 3)] = sc.inner[k];
+  __syncthreads();
+
+  const uint32_t n_waves = gridDim.x * (BLOCK / 64);
+  uint32_t pool_size = n_rays / (n_waves * a.pool_div);
+  pool_size = pool_size > a.pool_max ? a.pool_max : (pool_size < TRACE_POOL_MIN ? TRACE_POOL_MIN : pool_size);
+  uint32_t pool_next = 0, pool_end = 0; // wave-uniform pool of reserved ray indices
+  bool exhausted = false;               // wave-uniform: nothing left to reserve
+
+  bool nx_valid = false; // prefetched next ray of this lane
+  uint32_t nx_slot = 0;
+  float4 nx_o = make_float4(0, 0, 0, 0), nx_d = make_float4(0, 0, 0, 0);
+
+  bool work = false; // current ray
+  bool wild = false; // ... needs the exact NaN-aware slab test
+  uint32_t slot = 0;
+  f3 S = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
+  float best_t = INF;
+  int32_t best_tri = -1;
+  int sp = 0;
+  uint32_t ref = 0;
+  Counters ctr = {0, 0, 0, 0, 0, 0, 0};
+  uint32_t ray_p0 = 0, ray_t0 = 0, ray_i0 = 0, iters = 0;
+
+  for (;;) {
+    if (FULLCTR) iters++;
+    // ---- refill: lanes without work adopt their prefetched ray, then prefetch another
+    const bool want = !work;
+    if (__ballot(want)) {
+      if (want && nx_valid) {
+        nx_valid = false;
+        if (nx_d.w != 0.0f) {
+          work = true;
+          slot = nx_slot;
+          S = mk(nx_o.x, nx_o.y, nx_o.z);
+          d = mk(nx_d.x, nx_d.y, nx_d.z);
+          inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+          wild = !ray_is_tame(S, inv);
+          best_t = INF;
+          best_tri = -1;
+          sp = 0;
+          ref = sc.root_ref;
+          ctr.rays++;
+          if (FULLCTR) {
+            ray_p0 = ctr.pops;
+            ray_t0 = ctr.tris;
+            ray_i0 = iters;
+            ctr.pops++;
+          }
+        }
+      }
+      const bool need = !nx_valid && !exhausted;
+      const unsigned long long m = __ballot(need);
+      if (m) {
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        const uint32_t r = lane_rank(m);
+        uint32_t idx;
+        bool served;
+        if (pool_end - pool_next < cnt) { // wave-uniform: top the pool up with one atomic
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(a.head, pool_size);
+          base = __shfl(base, 0, 64);
+          const uint32_t left = pool_end - pool_next; // hand out the old pool's rest first
+          uint32_t take = cnt - left;
+          if (take > pool_size) take = pool_size;
+          idx = (r < left) ? (pool_next + r) : (base + (r - left));
+          served = r < left + take;
+          pool_next = base + take;
+          pool_end = base + pool_size;
+          if (base >= n_rays) exhausted = true;
+        } else {
+          idx = pool_next + r;
+          served = true;
+          pool_next += cnt;
+          if (pool_next >= n_rays && pool_end >= n_rays) exhausted = true;
+        }
+        if (need && served && idx < n_rays) {
+          nx_slot = idx;
+          nx_o = a.rq.o[idx];
+          nx_d = a.rq.d[idx];
+          nx_valid = true;
+        }
+      }
+    }
+    if (!__ballot(work || nx_valid)) break;
+
+    // ---- inner step for every lane standing on an inner node (P5/fsh:277-302)
+    const bool at_inner = work && !(ref & LEAF_BIT);
+    if (at_inner) {
+      if (FULLCTR) ctr.inner++;
+      float4 q0, q1, q2, q3;
+      if (ref < (uint32_t)a.lds_nodes) { // top of the tree: staged in LDS
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) const v4f lds_v4f;
+        lds_v4f* r = (lds_v4f*)(lds_nodes + ref * 5u);
+        const v4f w0 = r[0], w1 = r[1], w2 = r[2], w3 = r[3];
+        q0 = make_float4(w0.x, w0.y, w0.z, w0.w);
+        q1 = make_float4(w1.x, w1.y, w1.z, w1.w);
+        q2 = make_float4(w2.x, w2.y, w2.z, w2.w);
+        q3 = make_float4(w3.x, w3.y, w3.z, w3.w);
+      } else {
+        const float4* r = sc.inner + (size_t)ref * 4;
+        q0 = r[0];
+        q1 = r[1];
+        q2 = r[2];
+        q3 = r[3];
+      }
+      float d1, d2;
+      if (__ballot(wild)) { // some lane's ray has a zero/NaN direction component: exact select form
+        d1 = hit_aabb(S, inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));
+        d2 = hit_aabb(S, inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w));
+      } else {
+        d1 = hit_aabb_tame(S, inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));
+        d2 = hit_aabb_tame(S, inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w));
+      }
+      const uint32_t left = __float_as_uint(q3.x), right = __float_as_uint(q3.y);
+      const bool h1 = d1 > 0.0f, h2 = d2 > 0.0f;
+      if (h1 && h2) {
+        const bool lf = d1 < d2; // left first; on a tie the right child goes first
+        stack[sp * BLOCK] = (int)(lf ? right : left);
+        sp++;
+        ref = lf ? left : right;
+        if (FULLCTR) ctr.pops++;
+      } else if (h1 || h2) {
+        ref = h1 ? left : right;
+        if (FULLCTR) ctr.pops++;
+      } else if (sp > 0) {
+        sp--;
+        ref = (uint32_t)stack[sp * BLOCK];
+        if (FULLCTR) ctr.pops++;
+      } else {
+        a.hits[slot] = make_int2(best_tri, __float_as_int(best_t));
+        work = false;
+        if (FULLCTR && a.dbg) {
+          atomicMax(a.dbg, ctr.pops - ray_p0);
+          atomicMax(a.dbg + 1, ctr.tris - ray_t0);
+          atomicMax(a.dbg + 2, iters - ray_i0);
+        }
+      }
+    }
+
+    // ---- leaf phase (hitArray, P5/fsh:238-251): postponed until enough lanes wait at a leaf, or
+    // nobody can step.  (Issuing the node and triangle fetches of one iteration together was tried:
+    // +22 VGPRs cost a wave per SIMD and 10 % -- see DESIGN.md.)
+    const bool at_leaf = work && (ref & LEAF_BIT);
+    const unsigned long long lm = __ballot(at_leaf);
+    if (lm) {
+      const int Lc = (int)__popcll(lm);
+      const bool go = Lc >= a.leaf_threshold || !__ballot(work && !(ref & LEAF_BIT));
+      if (go) {
+        if (!FULLCTR && Lc <= 32) {
+          // cooperative: g = 64 / Lc lanes (power of two) per waiting ray
+          const int sh = (Lc <= 1) ? 0 : (32 - __clz(Lc - 1));
+          const int g = 64 >> sh;
+          const uint32_t rank = lane_rank(lm);
+          if (at_leaf) wsrc[rank] = lane;
+          __builtin_amdgcn_wave_barrier();
+          const int grp = lane >> (6 - sh), m = lane & (g - 1);
+          const bool helper = grp < Lc;
+          const int src = helper ? wsrc[grp] : lane;
+          const f3 cS = mk(__shfl(S.x, src, 64), __shfl(S.y, src, 64), __shfl(S.z, src, 64));
+          const f3 cd = mk(__shfl(d.x, src, 64), __shfl(d.y, src, 64), __shfl(d.z, src, 64));
+          const uint32_t lref = (uint32_t)__shfl((int)ref, src, 64);
+          unsigned long long key = ~0ull;
+          if (helper) {
+            const int first = (int)(lref & 0x00ffffffu);
+            const int n = (int)((lref >> 24) & 0x7fu) + 1;
+            for (int k = m; k < n; k += g) {
+              float t;
+              if (hit_triangle_t(sc.tri_geom + (size_t)(first + k) * 3, cS, cd, t)) {
+                const unsigned long long k2 = ((unsigned long long)__float_as_uint(t) << 32) | (uint32_t)(first + k);
+                key = k2 < key ? k2 : key;
+              }
+            }
+          }
+          for (int off = 1; off < g; off <<= 1) {
+            const unsigned long long other = __shfl_xor(key, off, 64);
+            key = other < key ? other : key;
+          }
+          const unsigned long long mine = __shfl(key, (int)(rank << (6 - sh)), 64);
+          if (at_leaf && mine != ~0ull) {
+            const float t = __uint_as_float((uint32_t)(mine >> 32));
+            if (t < best_t) {
+              best_t = t;
+              best_tri = (int32_t)(uint32_t)mine;
+            }
+          }
+        } else if (at_leaf) {
+          const int first = (int)(ref & 0x00ffffffu);
+          const int n = (int)((ref >> 24) & 0x7fu) + 1;
+          float leaf_best = INF; // hitArray's local res: only the M counter needs it
+          for (int i = first; i < first + n; i++) {
+            float t;
+            const bool hit = hit_triangle_t(sc.tri_geom + (size_t)i * 3, S, d, t);
+            if (FULLCTR) {
+              ctr.tris++;
+              if (hit && t < leaf_best) {
+                leaf_best = t;
+                ctr.mats++;
+              }
+            }
+            if (hit && t < best_t) {
+              best_t = t;
+              best_tri = i;
+            }
+          }
+        }
+        if (at_leaf) {
+          if (sp > 0) {
+            sp--;
+            ref = (uint32_t)stack[sp * BLOCK];
+            if (FULLCTR) ctr.pops++;
+          } else {
+            a.hits[slot] = make_int2(best_tri, __float_as_int(best_t));
+            work = false;
+            if (FULLCTR && a.dbg) {
+              atomicMax(a.dbg, ctr.pops - ray_p0);
+              atomicMax(a.dbg + 1, ctr.tris - ray_t0);
+              atomicMax(a.dbg + 2, iters - ray_i0);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  const unsigned long long rr = wave_sum(ctr.rays);
+  if (lane == 0 && rr) atomicAdd(&a.counters[EZRT_CTR_RAYS], rr);
+  if (FULLCTR) {
+    const unsigned long long v1 = wave_sum(ctr.pops), v2 = wave_sum(ctr.inner), v3 = wave_sum(ctr.tris),
+                             v4 = wave_sum(ctr.mats);
+    if (lane == 0) {
+      atomicAdd(&a.counters[EZRT_CTR_NODE_POPS], v1);
+      atomicAdd(&a.counters[EZRT_CTR_INNER_POPS], v2);
+      atomicAdd(&a.counters[EZRT_CTR_TRI_TESTS], v3);
+      atomicAdd(&a.counters[EZRT_CTR_MAT_FETCH], v4);
+    }
+  }
+}
+
+} // namespace ezd

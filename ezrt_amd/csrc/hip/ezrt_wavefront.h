@@ -22,15 +22,13 @@
 // slot).  The megakernel stays as the path-audit implementation (ezrt_render_paths).
 #pragma once
 #include "ezrt_kernels.h"
+#include "ezrt_traceq.h"
 
 namespace ezd {
 
 constexpr uint32_t FLAG_SHADOW_SHOT = 1u;  // slot 2i holds a live env shadow ray
 constexpr uint32_t FLAG_TERMINATE = 2u;    // NdotL <= 0 (P5/fsh:854): finish after the shadow result
 constexpr uint32_t FLAG_PDF_DEAD = 4u;     // pdf_brdf <= 0 (P5/fsh:865): ray shot, then break
-constexpr uint32_t TRACE_POOL_MAX = 2048;  // ray indices a wave reserves per atomic (large queues)
-constexpr uint32_t TRACE_POOL_MIN = 8;     // ... small queues are spread over every resident wave
-
 struct PathState { // SoA of float4, one slot per live path
   float4* s0; // history.xyz, cosine
   float4* s1; // Lo.xyz, pdf
@@ -38,11 +36,6 @@ struct PathState { // SoA of float4, one slot per live path
   float4* s3; // Le0.xyz, bits(seed)
   float4* s4; // shadow contribution.xyz, bits(flags)          (integrator 51 only)
 };
-struct RayQueue {
-  float4* o; // origin.xyz, -
-  float4* d; // dir.xyz, valid (1) / skip (0)
-};
-
 struct WfArgs {
   DevScene sc;
   EzrtRenderParams p;
@@ -100,264 +93,6 @@ __global__ __launch_bounds__(BLOCK) void raygen_kernel(WfArgs a) {
   a.rq_out.o[slot] = make_float4(p.eye[0], p.eye[1], p.eye[2], 0.0f);
   a.rq_out.d[slot] = make_float4(dir.x, dir.y, dir.z, 1.0f);
   a.st_out.s3[slot] = make_float4(0, 0, 0, __uint_as_float(seed));
-}
-
-// ---------------------------------------------------------------------------
-// persistent queue traversal
-struct TraceQArgs {
-  DevScene sc;
-  RayQueue rq;
-  int2* hits;
-  const uint32_t* n_paths; // device count; rays = n_paths * rays_per_path
-  uint32_t rays_per_path;
-  uint32_t* head;          // queue head (device, zeroed per launch)
-  unsigned long long* counters;
-  int32_t leaf_threshold;  // lanes waiting at a leaf that trigger the triangle phase
-  uint32_t pool_div, pool_max; // pool = clamp(n_rays / (n_waves * pool_div), 8, pool_max)
-  int32_t stack_entries;   // LDS stack rows (tree depth); the per-wave lane table follows them
-  uint32_t* dbg;           // diagnostic (FULLCTR only): [0] max pops/ray [1] max tris/ray [2] max loop iterations/ray
-};
-
-EZD uint32_t lane_rank(unsigned long long mask) { // number of set bits below this lane
-  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
-
-template <bool FULLCTR, int WPS>
-__global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
-  extern __shared__ __attribute__((aligned(16))) int lds_stack[];
-  int* stack = lds_stack + threadIdx.x;
-  const DevScene& sc = a.sc;
-  const uint32_t n_rays = (*a.n_paths) * a.rays_per_path;
-  const int lane = threadIdx.x & 63;
-  // reservation size: a short queue (late bounces: few, deep rays) is dealt out in small pools so
-  // that every resident wave gets a few lanes of work instead of a few waves getting all of it
-  const uint32_t n_waves = gridDim.x * (BLOCK / 64);
-  // (one queue-head word sustains only ~88 atomics/us chip-wide -- MI355X_MICROARCH.md "dequeue" --
-  // so a wave takes ~1/4 of its fair share per atomic: <= ~4 atomics per wave per launch)
-  uint32_t pool_size = n_rays / (n_waves * a.pool_div);
-  pool_size = pool_size > a.pool_max ? a.pool_max : (pool_size < TRACE_POOL_MIN ? TRACE_POOL_MIN : pool_size);
-
-  // wave-uniform pool of reserved ray indices
-  uint32_t pool_next = 0, pool_end = 0;
-  bool exhausted = false; // wave-uniform: the queue has no more rays to hand out
-
-  // prefetched next ray of this lane
-  bool nx_valid = false;
-  uint32_t nx_slot = 0;
-  float4 nx_o = make_float4(0, 0, 0, 0), nx_d = make_float4(0, 0, 0, 0);
-
-  // current ray
-  bool work = false;
-  bool wild = false; // current ray needs the exact NaN-aware slab test
-  uint32_t slot = 0;
-  f3 S = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
-  float best_t = INF;
-  int32_t best_tri = -1;
-  int sp = 0;
-  uint32_t ref = 0;
-  float leaf_best = INF;
-  Counters ctr = {0, 0, 0, 0, 0, 0, 0};
-  uint32_t ray_p0 = 0, ray_t0 = 0, ray_i0 = 0, iters = 0;
-
-  for (;;) {
-    if (FULLCTR) iters++;
-    // ---- refill: lanes without work adopt their prefetched ray, then prefetch another
-    const bool want = !work;
-    if (__ballot(want)) {
-      if (want && nx_valid) {
-        nx_valid = false;
-        if (nx_d.w != 0.0f) {
-          work = true;
-          slot = nx_slot;
-          S = mk(nx_o.x, nx_o.y, nx_o.z);
-          d = mk(nx_d.x, nx_d.y, nx_d.z);
-          inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-          wild = !ray_is_tame(S, inv);
-          best_t = INF;
-          best_tri = -1;
-          sp = 0;
-          ref = sc.root_ref;
-          ctr.rays++;
-          if (FULLCTR) { ray_p0 = ctr.pops; ray_t0 = ctr.tris; ray_i0 = iters; ctr.pops++; }
-        }
-      }
-      // lanes with an empty prefetch register reserve the next indices
-      const bool need = !nx_valid && !exhausted;
-      unsigned long long m = __ballot(need);
-      if (m) {
-        uint32_t cnt = (uint32_t)__popcll(m);
-        if (pool_end - pool_next < cnt) { // wave-uniform: top the pool up with one atomic
-          uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(a.head, pool_size);
-          base = __shfl(base, 0, 64);
-          // hand out what is left of the old pool first, then the head of the new one; a pool
-          // smaller than the request leaves some lanes without a prefetch until the next round
-          uint32_t left = pool_end - pool_next;
-          uint32_t r = lane_rank(m);
-          uint32_t idx = (r < left) ? (pool_next + r) : (base + (r - left));
-          uint32_t take = cnt - left;
-          if (take > pool_size) take = pool_size;
-          const bool served = r < left + take;
-          pool_next = base + take;
-          pool_end = base + pool_size;
-          if (need && served) {
-            if (idx < n_rays) {
-              nx_slot = idx;
-              nx_o = a.rq.o[idx];
-              nx_d = a.rq.d[idx];
-              nx_valid = true;
-            }
-          }
-          if (base >= n_rays) exhausted = true;
-        } else {
-          uint32_t idx = pool_next + lane_rank(m);
-          pool_next += cnt;
-          if (need) {
-            if (idx < n_rays) {
-              nx_slot = idx;
-              nx_o = a.rq.o[idx];
-              nx_d = a.rq.d[idx];
-              nx_valid = true;
-            }
-          }
-          if (pool_next >= n_rays && pool_end >= n_rays) exhausted = true;
-        }
-      }
-    }
-    if (!__ballot(work || nx_valid)) break;
-
-    // ---- inner step for every lane standing on an inner node
-    const bool at_inner = work && !(ref & LEAF_BIT);
-    if (at_inner) {
-      if (FULLCTR) ctr.inner++;
-      const float4* r = sc.inner + (size_t)ref * 4;
-      float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
-      float d1, d2;
-      if (__ballot(wild)) { // some lane's ray has a zero/NaN direction component: exact select-based min/max
-        d1 = hit_aabb(S, inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));
-        d2 = hit_aabb(S, inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w));
-      } else {
-        d1 = hit_aabb_tame(S, inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));
-        d2 = hit_aabb_tame(S, inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w));
-      }
-      uint32_t left = __float_as_uint(q3.x), right = __float_as_uint(q3.y);
-      bool h1 = d1 > 0.0f, h2 = d2 > 0.0f;
-      if (h1 && h2) {
-        bool lf = d1 < d2; // left first
-        stack[sp * BLOCK] = (int)(lf ? right : left);
-        sp++;
-        ref = lf ? left : right;
-        if (FULLCTR) ctr.pops++;
-      } else if (h1 || h2) {
-        ref = h1 ? left : right;
-        if (FULLCTR) ctr.pops++;
-      } else if (sp > 0) {
-        sp--;
-        ref = (uint32_t)stack[sp * BLOCK];
-        if (FULLCTR) ctr.pops++;
-      } else { // traversal finished
-        a.hits[slot] = make_int2(best_tri, __float_as_int(best_t));
-        work = false;
-        if (FULLCTR && a.dbg) { atomicMax(a.dbg, ctr.pops - ray_p0); atomicMax(a.dbg + 1, ctr.tris - ray_t0); atomicMax(a.dbg + 2, iters - ray_i0); }
-      }
-    }
-
-    // ---- leaf phase: postponed until enough lanes wait at a leaf, or nobody can step
-    const bool at_leaf = work && (ref & LEAF_BIT);
-    unsigned long long lm = __ballot(at_leaf);
-    if (lm) {
-      bool go = (int)__popcll(lm) >= a.leaf_threshold || !__ballot(work && !(ref & LEAF_BIT));
-      if (go) {
-        const int Lc = (int)__popcll(lm);
-        if (!FULLCTR && Lc <= 32) {
-          // Cooperative leaf phase: the Lc waiting rays share the whole wave.  g = 64 / Lc lanes
-          // (power of two) work for each ray, lane m of a group testing triangles m, m+g, ... of
-          // that ray's leaf, so a leaf of <= g triangles costs ONE dependent round instead of n.
-          // The group minimum of (t bits << 32 | triangle index) is the first triangle (in leaf
-          // order) with the smallest t -- exactly hitArray's strict-< scan (P5/fsh:242-249).
-          const int sh = (Lc <= 1) ? 0 : (32 - __clz(Lc - 1));
-          const int g = 64 >> sh;
-          int* wsrc = lds_stack + a.stack_entries * BLOCK + (threadIdx.x >> 6) * 64;
-          const uint32_t rank = lane_rank(lm);
-          if (at_leaf) wsrc[rank] = lane;
-          __builtin_amdgcn_wave_barrier();
-          const int grp = lane >> (6 - sh), m = lane & (g - 1);
-          const bool helper = grp < Lc;
-          const int src = helper ? wsrc[grp] : lane;
-          const float sx = __shfl(S.x, src, 64), sy = __shfl(S.y, src, 64), sz = __shfl(S.z, src, 64);
-          const float dx = __shfl(d.x, src, 64), dy = __shfl(d.y, src, 64), dz = __shfl(d.z, src, 64);
-          const uint32_t lref = (uint32_t)__shfl((int)ref, src, 64);
-          unsigned long long key = ~0ull;
-          if (helper) {
-            const int first = (int)(lref & 0x00ffffffu);
-            const int n = (int)((lref >> 24) & 0x7fu) + 1;
-            for (int k = m; k < n; k += g) {
-              float t;
-              bool hit = hit_triangle_t(sc.tri_geom + (size_t)(first + k) * 3, mk(sx, sy, sz), mk(dx, dy, dz), t);
-              if (hit) {
-                unsigned long long k2 = ((unsigned long long)__float_as_uint(t) << 32) | (uint32_t)(first + k);
-                key = k2 < key ? k2 : key;
-              }
-            }
-          }
-          for (int off = 1; off < g; off <<= 1) {
-            unsigned long long other = __shfl_xor(key, off, 64);
-            key = other < key ? other : key;
-          }
-          const unsigned long long mine = __shfl(key, (int)(rank << (6 - sh)), 64);
-          if (at_leaf && mine != ~0ull) {
-            float t = __uint_as_float((uint32_t)(mine >> 32));
-            if (t < best_t) {
-              best_t = t;
-              best_tri = (int32_t)(uint32_t)mine;
-            }
-          }
-        } else if (at_leaf) {
-          int first = (int)(ref & 0x00ffffffu);
-          int n = (int)((ref >> 24) & 0x7fu) + 1;
-          if (FULLCTR) leaf_best = INF;
-          for (int i = first; i < first + n; i++) {
-            float t;
-            bool hit = hit_triangle_t(sc.tri_geom + (size_t)i * 3, S, d, t);
-            if (FULLCTR) {
-              ctr.tris++;
-              if (hit && t < leaf_best) {
-                leaf_best = t;
-                ctr.mats++;
-              }
-            }
-            if (hit && t < best_t) {
-              best_t = t;
-              best_tri = i;
-            }
-          }
-        }
-        if (at_leaf) {
-          if (sp > 0) {
-            sp--;
-            ref = (uint32_t)stack[sp * BLOCK];
-            if (FULLCTR) ctr.pops++;
-          } else {
-            a.hits[slot] = make_int2(best_tri, __float_as_int(best_t));
-            work = false;
-            if (FULLCTR && a.dbg) { atomicMax(a.dbg, ctr.pops - ray_p0); atomicMax(a.dbg + 1, ctr.tris - ray_t0); atomicMax(a.dbg + 2, iters - ray_i0); }
-          }
-        }
-      }
-    }
-  }
-
-  unsigned long long rr = wave_sum(ctr.rays);
-  if (lane == 0 && rr) atomicAdd(&a.counters[EZRT_CTR_RAYS], rr);
-  if (FULLCTR) {
-    unsigned long long v1 = wave_sum(ctr.pops), v2 = wave_sum(ctr.inner), v3 = wave_sum(ctr.tris), v4 = wave_sum(ctr.mats);
-    if (lane == 0) {
-      atomicAdd(&a.counters[EZRT_CTR_NODE_POPS], v1);
-      atomicAdd(&a.counters[EZRT_CTR_INNER_POPS], v2);
-      atomicAdd(&a.counters[EZRT_CTR_TRI_TESTS], v3);
-      atomicAdd(&a.counters[EZRT_CTR_MAT_FETCH], v4);
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------

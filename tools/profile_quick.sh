@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 "$@" > $OUT/stats.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 "$@" > $OUT/stats.log 2>&1
 python3 - <<PY
 import csv
 rows = list(csv.DictReader(open("$OUT/stats/s_kernel_stats.csv")))
