@@ -211,3 +211,31 @@ CONFIGS = {
     "C3": dict(width=1024, height=1024, spp=128, max_bounce=4, integrator=INTEGRATOR_P4_DISNEY, camera=(0, 15, 8)),
     "C4": dict(width=1024, height=1024, spp=256, max_bounce=2, integrator=INTEGRATOR_P5_MIS, camera=(90, 10, 2)),
 }
+
+
+def disney_grid_scene(subdiv=3, hdr="synthetic", leaf_n=8):
+    """C3: 5x5 grid of spheres (sphere.obj subdivided `subdiv` times: 3 -> 20 480 faces each, the
+    face count of the reference's sphere2.obj), metallic in {0,.25,.5,.75,1} x roughness in
+    {.1,.2,.3,.5,.8}, baseColor (0.75,0.7,0.15), clearcoat 1, over a floor box -- the sweeps of
+    T4 tutorial.md:487-491 / P4/main.cpp:696-714 extended to a grid.  NEAREST env (P4 filter)."""
+    hs = S.HostScene()
+    sv, sf = mesh("sphere")
+    if subdiv:
+        sv, sf = subdivide(sv, sf, subdiv)
+        # push the new vertices back onto the sphere (float32): midpoint subdivision alone keeps facets
+        c = sv.mean(axis=0, dtype=np.float32)
+        r = np.sqrt(((sv[:162] - c) ** 2).sum(1)).mean(dtype=np.float32)
+        dv = sv - c
+        ln = np.sqrt((dv * dv).sum(1, dtype=np.float32)).astype(np.float32)
+        sv = (c + dv * (r / ln)[:, None]).astype(np.float32)
+    text = obj_text(sv, sf)
+    for i, metallic in enumerate((0.0, 0.25, 0.5, 0.75, 1.0)):
+        for j, rough in enumerate((0.1, 0.2, 0.3, 0.5, 0.8)):
+            m = S.Material.disney(baseColor=(0.75, 0.7, 0.15), metallic=metallic, roughness=rough, clearcoat=1.0)
+            hs.readObjText(text, m, S.getTransformMatrix((0, 0, 0), (-2.4 + 1.2 * i, -0.9 + 0.0 * j, -2.4 + 1.2 * j),
+                                                         (1.0, 1.0, 1.0)), True)
+    qv, qf = mesh("quad")
+    hs.readObjText(obj_text(qv, qf), S.Material.disney(baseColor=(0.725, 0.71, 0.68)),
+                   S.getTransformMatrix((0, 0, 0), (0, -1.4, 0), (18.83, 0.01, 18.83)), False)
+    h = synthetic_hdr() if isinstance(hdr, str) and hdr == "synthetic" else hdr
+    return _finish("disney_grid_sub%d" % subdiv, hs, leaf_n, h, False, FILTER_NEAREST)
