@@ -9,7 +9,10 @@ are resident in HBM before the timed region.  ray := one hitBVH call, counted by
 
 N > 1: one process per GPU (torchrun); the image is split into 16x16 tiles dealt round-robin to the
 ranks (scene replicated), each rank traces its tiles, then ONE gather of the packed tiles to rank 0
-over RCCL closes the frame.  Total work is fixed => "scaling": "strong".
+over RCCL closes the frame.  Default "scaling": "weak": at N GPUs the frame is rendered at 64 x N spp,
+so every GPU keeps the 1-GPU number of pixel-samples (16.8 M) on its 1/N of the tiles; `--scaling strong`
+splits the 64-spp frame N ways instead (the late bounces are latency-bound and do not shrink with
+the ray count, so strong scaling of a 5 ms frame is poor by construction -- DESIGN.md section 7).
 
 Prints one JSON line on rank 0 (contract in the task statement) with `roofline` and, at N = 1,
 `cpu_baseline` (the CPU oracle timed on a bounded sample of the same workload).
@@ -47,6 +50,9 @@ def main():
     ap.add_argument("--integrator", type=int, default=50)
     ap.add_argument("--subdiv", type=int, default=2)
     ap.add_argument("--tile", type=int, default=16)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every GPU keeps the 1-GPU number of pixel-samples (spp x n_gpus on 1/n of the "
+                         "tiles); strong: the 1-GPU frame is split n ways")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time (0 = skip)")
     ap.add_argument("--save-png", default="")
     args = ap.parse_args()
@@ -64,11 +70,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the trace has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # EZRT_BENCH_BACKEND=gloo is a debugging aid for boxes with fewer GPUs than ranks: the ranks share
+    # GPU 0 and the gather is staged through host memory.  The driver's runs use nccl (= RCCL).
+    backend = os.environ.get("EZRT_BENCH_BACKEND", "nccl")
+    gpu_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from ezrt_amd import scene as S, scenes, tiles, trace
     hip = trace.hip()  # after torch: shares torch's HIP runtime (same soname)
@@ -80,7 +93,8 @@ def main():
     sc = bs.upload(hip)
     eye, cam = S.camera(0, 0, 4)
     W, H = args.width, args.height
-    p = trace.make_params(W, H, eye, cam, args.integrator, args.bounces, spp=args.spp, tile=(args.tile, args.tile),
+    spp = args.spp * world if args.scaling == "weak" else args.spp
+    p = trace.make_params(W, H, eye, cam, args.integrator, args.bounces, spp=spp, tile=(args.tile, args.tile),
                           shard=(rank, world))
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     plan = tiles.TilePlan(W, H, args.tile, args.tile, world) if world > 1 else None
@@ -89,7 +103,7 @@ def main():
     def step():
         sc.render_device(p, accum.data_ptr(), stream)
         if world > 1:
-            return tiles.gather_frame(accum, plan, rank, dist)
+            return tiles.gather_frame(accum, plan, rank, dist, via_cpu=(backend != "nccl"))
         return accum
 
     def barrier():
@@ -113,7 +127,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     rays_local = sc.counters()["rays"]
-    tt = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=dev)
+    tt = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -126,12 +140,14 @@ def main():
     out = {
         "metric": "Mrays/s at fixed spp (Bunny ~70k tris, 4 bounces)",
         "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+        "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 4), "higher_is_better": True,
+        "scaling": args.scaling if world > 1 else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "C2: P3 scene, Stanford Bunny subdivided x%d (%d tris, %d BVH nodes, SAH leaf 8), "
-                               "%dx%d, integrator %d, %d bounces, %d spp, procedural 1024x512 env"
+                               "%dx%d, integrator %d, %d bounces, %d spp%s, procedural 1024x512 env"
                                % (args.subdiv, bs.tri.shape[0], bs.nodes.shape[0], W, H, args.integrator, args.bounces,
-                                  args.spp),
+                                  spp, (" (= %d spp x %d GPUs: per-GPU pixel-samples fixed)" % (args.spp, world))
+                                  if (world > 1 and args.scaling == "weak") else ""),
                    "rays_per_step": int(rays_per_step), "ray_definition": "one hitBVH call",
                    "parallelism": "tiles%dx%d round-robin over %d GPU(s), 1 RCCL gather/frame" % (args.tile, args.tile, world),
                    "scene_build_s": round(t_build, 3)},

@@ -67,13 +67,18 @@ class TilePlan:
         return self.from_tiles(tiles)
 
 
-def gather_frame(accum, plan, rank, dist, dst=0):
+def gather_frame(accum, plan, rank, dist, dst=0, via_cpu=False):
     """Close a frame: one gather of every rank's packed tiles to `dst`.  Returns the assembled
-    [H, W, C] frame on `dst` and the rank's own buffer elsewhere."""
+    [H, W, C] frame on `dst` and the rank's own buffer elsewhere.  via_cpu stages the payload
+    through host memory (gloo debugging of the GPU driver script; never used with RCCL)."""
     packed = plan.pack(accum, rank)
+    if via_cpu:
+        packed = packed.cpu()
     if rank == dst:
         bufs = [torch.empty_like(packed) for _ in range(plan.world)]
         dist.gather(packed, gather_list=bufs, dst=dst)
+        if via_cpu:
+            bufs = [b.to(accum.device) for b in bufs]
         return plan.unpack(bufs)
     dist.gather(packed, gather_list=None, dst=dst)
     return accum
