@@ -54,6 +54,7 @@ TRACE_ABI = {
     "ezrt_query_hits": (C.c_int, [C.c_void_p, c_float_p, C.c_int, c_int32_p, c_float_p]),
     "ezrt_tonemap": (C.c_int, [c_float_p, C.c_int, c_uint8_p]),
     "ezrt_sobol": (C.c_int, [C.c_uint32, C.c_int, C.c_int, c_float_p]),
+    "ezrt_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "ezrt_set_instrumentation": (C.c_int, [C.c_void_p, C.c_int]),
     "ezrt_counters": (C.c_int, [C.c_void_p, c_uint64_p]),
     "ezrt_counters_reset": (C.c_int, [C.c_void_p]),

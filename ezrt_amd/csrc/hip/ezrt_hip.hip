@@ -13,6 +13,7 @@
 #include "ezrt.h"
 #include "ezrt_kernels.h"
 #include "ezrt_wavefront.h"
+#include "ezrt_tracepk.h"
 
 using namespace ezd;
 
@@ -54,6 +55,38 @@ struct DevBuf {
 
 constexpr int MAX_TRACE_EVENTS = 64;
 
+// Schedule knobs (never change results).  Defaults = the tuned values for C2 on MI355X; an
+// environment variable EZRT_<NAME> overrides the default at scene creation, ezrt_set_option at run time.
+struct Tuning {
+  int megakernel = 0;      // 1: v1 one-lane-per-path kernel instead of the streaming pipeline
+  int packet = 0;          // 1: packet traversal for primary rays (slower on C2: 1.48+0.61 ms vs 1.55 ms)
+  int packet_budget = 48;  // steps after which a packet hands its rays to the per-lane kernel
+  int leaf_threshold = 4;  // lanes waiting at a leaf that trigger the triangle phase
+  int pool_div = 1;        // ray-index pool = clamp(n_rays / (n_waves * pool_div), 8, pool_max)
+  int pool_max = 256;
+  int trace_wps = 5;       // traceq_kernel register budget: waves per SIMD (4, 5, 6 or 8)
+  int lds_nodes = 1 << 20; // cap on top-of-tree records staged in LDS
+  int debug_stages = 0;    // print per-stage queue sizes (synchronises)
+};
+struct TuningName {
+  const char* name;
+  int Tuning::*field;
+};
+const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel}, {"packet", &Tuning::packet},
+                              {"packet_budget", &Tuning::packet_budget}, {"leaf_threshold", &Tuning::leaf_threshold},
+                              {"pool_div", &Tuning::pool_div}, {"pool_max", &Tuning::pool_max},
+                              {"trace_wps", &Tuning::trace_wps}, {"lds_nodes", &Tuning::lds_nodes},
+                              {"debug_stages", &Tuning::debug_stages}};
+Tuning tuning_from_env() {
+  Tuning t;
+  for (const TuningName& k : kTuning) {
+    std::string env = "EZRT_";
+    for (const char* c = k.name; *c; c++) env += (char)((*c >= 'a' && *c <= 'z') ? (*c - 32) : *c);
+    if (const char* e = getenv(env.c_str())) t.*(k.field) = atoi(e);
+  }
+  return t;
+}
+
 } // namespace
 
 struct EzrtScene {
@@ -80,9 +113,12 @@ struct EzrtScene {
   DevBuf<float4> rq_o[2], rq_d[2];
   DevBuf<float4> st[2][5];
   DevBuf<int2> hits;
-  DevBuf<uint32_t> qcounts; // [0..63] path counts per stage, [64..127] trace queue heads
+  DevBuf<uint32_t> qcounts; // [0..63] path counts per stage, [64..99] trace queue heads, [100..115] debug,
+                            // [120] redo count, [121] redo queue head
+  DevBuf<uint32_t> redo_slots;
   int num_cus = 0;
   int n_inner = 0;
+  Tuning tune = tuning_from_env();
   // timing
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   hipEvent_t ev_trace[MAX_TRACE_EVENTS][2];
@@ -229,7 +265,7 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
   const bool full = s->instr > 0;
   const size_t n_slots = (size_t)nb * BLOCK * nf;
   const size_t n_rays_max = n_slots * (mis ? 2 : 1);
-  if (p->max_bounce + 2 > 64) return fail(EZRT_ERR_UNSUPPORTED, "max_bounce too large for the stage counters");
+  if (p->max_bounce > 32) return fail(EZRT_ERR_UNSUPPORTED, "max_bounce > 32: more stages than this build has queue counters for");
   for (int k = 0; k < 2; k++) {
     HIP_TRY(s->rq_o[k].ensure(n_rays_max));
     HIP_TRY(s->rq_d[k].ensure(n_rays_max));
@@ -281,16 +317,10 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
   hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((n_slots + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, a);
 
   const size_t lds = stack_lds_bytes(s);
-  static int trace_wps = -1;
-  if (trace_wps < 0) {
-    const char* e = getenv("EZRT_TRACE_WPS");
-    trace_wps = e ? atoi(e) : 5;
-  }
-  static int lds_nodes_max = -1;
-  if (lds_nodes_max < 0) {
-    const char* e = getenv("EZRT_LDS_NODES");
-    lds_nodes_max = e ? atoi(e) : 1 << 20;
-  }
+  const Tuning& tu = s->tune;
+  const int trace_wps = tu.trace_wps, lds_nodes_max = tu.lds_nodes, use_packet = tu.packet,
+            packet_budget = tu.packet_budget, debug_stages = tu.debug_stages, pool_div = tu.pool_div,
+            pool_max = tu.pool_max, leaf_thr = tu.leaf_threshold;
   // LDS per workgroup: traversal stack + lane table + as many top-of-tree records (80 B each) as fit
   // when the register budget's `trace_wps` waves/SIMD (= trace_wps workgroups of 256 per CU) are resident
   const size_t lds_fixed = lds + BLOCK * sizeof(int);
@@ -307,23 +337,6 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
   const unsigned trace_grid = (unsigned)(s->num_cus * blocks_per_cu);
   unsigned shade_grid = (unsigned)((n_slots + SHADE_BLOCK - 1) / SHADE_BLOCK);
   if (shade_grid > 2048u) shade_grid = 2048u;
-  static int debug_stages = -1;
-  if (debug_stages < 0) {
-    const char* e = getenv("EZRT_DEBUG_STAGES");
-    debug_stages = (e && atoi(e) != 0) ? 1 : 0;
-  }
-  static int pool_div = -1, pool_max = -1;
-  if (pool_div < 0) {
-    const char* e = getenv("EZRT_POOL_DIV");
-    pool_div = e ? atoi(e) : 1;
-    e = getenv("EZRT_POOL_MAX");
-    pool_max = e ? atoi(e) : 256;
-  }
-  static int leaf_thr = -1;
-  if (leaf_thr < 0) {
-    const char* e = getenv("EZRT_LEAF_THRESHOLD");
-    leaf_thr = e ? atoi(e) : 4;
-  }
 
   for (int b = 0; b <= p->max_bounce; b++) {
     const int in = b & 1, out = in ^ 1;
@@ -341,8 +354,35 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
     t.stack_entries = (int32_t)(lds / (BLOCK * sizeof(int)));
     t.lds_nodes = lds_nodes;
     t.dbg = debug_stages ? (s->qcounts.p + 100 + 4 * (b & 3)) : nullptr;
+    t.slot_map = nullptr;
     int e = s->n_trace_events;
     if (e < MAX_TRACE_EVENTS) HIP_TRY(hipEventRecord(s->ev_trace[e][0], st));
+    if (b == 0 && !full && use_packet) {
+      // primary rays: packet traversal (one wave = one 8x8 tile); rays with an exact distance tie are
+      // put on a redo list, which the per-lane kernel below then traces in the reference's order
+      HIP_TRY(s->redo_slots.ensure(n_slots));
+      TracePkArgs k;
+      k.tri_geom = s->tri_geom.p;
+      k.inner = s->inner.p;
+      k.root_ref = s->root_ref;
+      k.rq = queue(in);
+      k.hits = s->hits.p;
+      k.n_rays = (uint32_t)n_slots;
+      k.counters = s->counters.p;
+      k.redo_count = s->qcounts.p + 120;
+      k.redo_slots = s->redo_slots.p;
+      k.stack_entries = s->depth + 1;
+      k.budget = packet_budget;
+      k.dbg = debug_stages ? (s->qcounts.p + 116) : nullptr;
+      const size_t lds_pk = (size_t)(BLOCK / 64) * k.stack_entries * 3 * sizeof(int);
+      unsigned pk_grid = (unsigned)(s->num_cus * 7); // 66 VGPRs: 7 waves/SIMD = 7 workgroups of 4 waves per CU
+      if ((size_t)pk_grid * BLOCK > n_slots) pk_grid = (unsigned)((n_slots + BLOCK - 1) / BLOCK);
+      hipLaunchKernelGGL(tracepk_kernel, dim3(pk_grid), dim3(BLOCK), lds_pk, st, k);
+      t.slot_map = s->redo_slots.p;
+      t.n_paths = s->qcounts.p + 120;
+      t.head = s->qcounts.p + 121;
+      s->n_trace_launches++;
+    }
     if (full) hipLaunchKernelGGL((traceq_kernel<true, 6>), dim3(trace_grid), dim3(BLOCK), lds_t, st, t);
     else if (trace_wps == 8) hipLaunchKernelGGL((traceq_kernel<false, 8>), dim3(trace_grid), dim3(BLOCK), lds_t, st, t);
     else if (trace_wps == 5) hipLaunchKernelGGL((traceq_kernel<false, 5>), dim3(trace_grid), dim3(BLOCK), lds_t, st, t);
@@ -367,6 +407,11 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
       HIP_TRY(hipStreamSynchronize(st));
       HIP_TRY(hipMemcpy(q, s->qcounts.p + b, sizeof q, hipMemcpyDeviceToHost));
       HIP_TRY(hipMemcpy(c, s->counters.p, sizeof c, hipMemcpyDeviceToHost));
+      if (b == 0 && use_packet && !full) {
+        uint32_t pk[3] = {0, 0, 0};
+        HIP_TRY(hipMemcpy(pk, s->qcounts.p + 116, sizeof pk, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[ezrt] packet stage: wave inner steps %u, wave triangle steps %u, max steps of one wave %u\n", pk[0], pk[1], pk[2]);
+      }
       uint32_t dbg[3] = {0, 0, 0};
       HIP_TRY(hipMemcpy(dbg, s->qcounts.p + 100 + 4 * (b & 3), sizeof dbg, hipMemcpyDeviceToHost));
       HIP_TRY(hipMemset(s->qcounts.p + 100 + 4 * (b & 3), 0, sizeof dbg));
@@ -572,11 +617,7 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
     if (chunk < 1) chunk = 1;
     if (chunk > p->spp) chunk = p->spp;
     HIP_TRY(s->samples.ensure(per_frame * chunk));
-    static int use_mega = -1;
-    if (use_mega < 0) {
-      const char* e = getenv("EZRT_MEGAKERNEL");
-      use_mega = (e && atoi(e) != 0) ? 1 : 0;
-    }
+    const int use_mega = s->tune.megakernel;
     const size_t lds = stack_lds_bytes(s);
     for (uint32_t done = 0; done < p->spp;) {
       uint32_t nf = (uint32_t)((p->spp - done < chunk) ? (p->spp - done) : chunk);
@@ -728,6 +769,16 @@ int ezrt_sobol(uint32_t index0, int n, int n_dims, float* out) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, d.p, cnt * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
+}
+
+int ezrt_set_option(EzrtScene* s, const char* name, int value) {
+  if (!s || !name) return fail(EZRT_ERR_INVALID, "NULL argument");
+  for (const TuningName& k : kTuning)
+    if (strcmp(k.name, name) == 0) {
+      s->tune.*(k.field) = value;
+      return 0;
+    }
+  return fail(EZRT_ERR_INVALID, "unknown option '%s'", name);
 }
 
 int ezrt_set_instrumentation(EzrtScene* s, int level) {

@@ -40,6 +40,7 @@ struct TraceQArgs {
   int32_t lds_nodes;       // inner records [0, lds_nodes) staged in LDS (after stack + lane table)
   int32_t stack_entries;   // LDS stack rows (tree depth); the per-wave lane table follows them
   uint32_t* dbg;           // diagnostic (FULLCTR only): [0] max pops/ray [1] max tris/ray [2] max iterations/ray
+  const uint32_t* slot_map; // optional indirection: queue index -> ray slot (redo list of tracepk_kernel)
 };
 
 EZD uint32_t lane_rank(unsigned long long mask) { // number of set bits below this lane
@@ -132,9 +133,10 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
           if (pool_next >= n_rays && pool_end >= n_rays) exhausted = true;
         }
         if (need && served && idx < n_rays) {
-          nx_slot = idx;
-          nx_o = a.rq.o[idx];
-          nx_d = a.rq.d[idx];
+          const uint32_t rs = a.slot_map ? a.slot_map[idx] : idx;
+          nx_slot = rs;
+          nx_o = a.rq.o[rs];
+          nx_d = a.rq.d[rs];
           nx_valid = true;
         }
       }

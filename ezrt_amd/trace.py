@@ -103,6 +103,9 @@ class Scene:
         self._ck(self._tl.lib.ezrt_query_hits(self._h, _fp(rays), n, tri.ctypes.data_as(_abi.c_int32_p), _fp(t)))
         return tri, t
 
+    def set_option(self, name, value):
+        self._ck(self._tl.lib.ezrt_set_option(self._h, name.encode(), int(value)))
+
     def set_instrumentation(self, level):
         self._ck(self._tl.lib.ezrt_set_instrumentation(self._h, int(level)))
 

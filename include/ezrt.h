@@ -123,6 +123,11 @@ int ezrt_tonemap(const float* rgba, int n_pixels, uint8_t* rgb8);
  * sobol(d, grayCode(index0+i)), d < n_dims <= 8. */
 int ezrt_sobol(uint32_t index0, int n, int n_dims, float* out);
 
+/* Schedule knobs of the implementation ("packet", "leaf_threshold", "megakernel", ... -- listed in
+ * DESIGN.md).  They change how the work is scheduled on the GPU, never the results; unknown names
+ * are an error.  The oracle accepts and ignores every name. */
+int ezrt_set_option(EzrtScene* s, const char* name, int value);
+
 /* Instrumentation: level 0 counts rays + samples only (timed runs), level 1
  * also counts P/I/T/M and env lookups.  Counters accumulate until reset. */
 int ezrt_set_instrumentation(EzrtScene* s, int level);

@@ -1028,6 +1028,12 @@ int ezrt_sobol(uint32_t index0, int n, int n_dims, float* out) {
   return 0;
 }
 
+int ezrt_set_option(EzrtScene* s, const char* name, int value) {
+  (void)value;
+  if (!s || !name) return fail(EZRT_ERR_INVALID, "NULL argument");
+  return 0; /* scheduling knobs of the GPU implementation: nothing to schedule here */
+}
+
 int ezrt_set_instrumentation(EzrtScene* s, int level) {
   if (!s || level < 0 || level > 1) return fail(EZRT_ERR_INVALID, "bad instrumentation level");
   s->instr = level;

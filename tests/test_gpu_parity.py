@@ -200,3 +200,99 @@ def test_full_size_bunny_70k_properties_and_sampled_parity(hip, oracle):
     assert sg.counters() == so.counters()
     crop = full[rect[1]:rect[3], rect[0]:rect[2]]
     assert crop[..., :3].max() > 0.5
+
+
+@pytest.mark.parametrize("integ", [50, 51])
+def test_eight_bounces_wrap_the_sobol_table(hip, oracle, bunny_small, integ):
+    """BASELINE.json's stress config asks for 8 bounces; the shader's table has 8 dimensions = 4
+    bounces.  Defined here: dimensions wrap (d & 7).  GPU == oracle for max_bounce 8."""
+    sg, so = bunny_small.upload(hip), bunny_small.upload(oracle)
+    eye, cam = S.camera(10, 5, 2.5)
+    p = trace.make_params(72, 56, eye, cam, integ, 8, spp=3)
+    assert np.array_equal(_bits(sg.render(p)), _bits(so.render(p)))
+    tg, dg, _ = sg.render_paths(trace.make_params(72, 56, eye, cam, integ, 8, frame0=2))
+    to, do, _ = so.render_paths(trace.make_params(72, 56, eye, cam, integ, 8, frame0=2))
+    assert tg.shape[-1] == 17 and np.array_equal(tg, to) and np.array_equal(_bits(dg), _bits(do))
+    assert (tg[..., 10] >= -1).any()  # some paths really reach the 5th bounce
+
+
+def test_exact_distance_ties_follow_the_reference_visit_order(hip, oracle, bunny_small):
+    """Every triangle duplicated (identical copies => every hit is an exact tie in t between two
+    triangle ids that usually sit in different leaves).  The winner is decided by the reference's
+    visit order (near child first, ties right-first, strict <): the packet kernel must detect the ties
+    and hand those rays to the per-lane kernel; triangle ids must still equal the oracle's."""
+    twin = bunny_small.tri[:5300:7].copy()
+    twin[:, 21:24] = (0.9, 0.1, 0.1)  # the copy is red: the image shows which twin won each tie
+    tri = np.concatenate([bunny_small.tri[:5300:7], twin])
+    rng = np.random.default_rng(12)
+    tri = tri[rng.permutation(tri.shape[0])]
+    hs = S.HostScene()
+    hs.addTriangles(tri)
+    hs.buildBVHwithSAH(8)
+    t2, n2 = hs.encode()
+    sg, so = hip.scene_create(t2, n2), oracle.scene_create(t2, n2)
+    hdr = scenes.synthetic_hdr(64, 32)
+    sg.set_env(hdr, None, 1)
+    so.set_env(hdr, None, 1)
+    eye, cam = S.camera(0, 0, 4)
+    p = trace.make_params(128, 128, eye, cam, 50, 3, spp=3)
+    io = so.render(p)
+    for packet, budget in ((0, 48), (1, 48), (1, 4), (1, 100000)):
+        sg.set_option("packet", packet)
+        sg.set_option("packet_budget", budget)
+        assert np.array_equal(_bits(sg.render(p)), _bits(io)), (packet, budget)
+    sg.counters_reset()
+    sg.render(p)
+    so.counters_reset()
+    so.render(p)
+    assert sg.counters()["rays"] == so.counters()["rays"]
+    tg, dg, _ = sg.render_paths(trace.make_params(128, 128, eye, cam, 50, 3, frame0=1))
+    to, do, _ = so.render_paths(trace.make_params(128, 128, eye, cam, 50, 3, frame0=1))
+    assert np.array_equal(tg, to) and (tg[..., 0] >= 0).mean() > 0.02
+
+
+def test_schedule_knobs_never_change_results(hip, bunny_small):
+    """ezrt_set_option only reschedules the same arithmetic: every combination is bit-identical."""
+    sg = bunny_small.upload(hip)
+    eye, cam = S.camera(0, 0, 4)
+    p = trace.make_params(160, 120, eye, cam, 51, 2, spp=3)
+    ref = sg.render(p)
+    for opts in ({"megakernel": 1}, {"packet": 1}, {"packet": 1, "packet_budget": 8}, {"leaf_threshold": 1},
+                 {"leaf_threshold": 64}, {"pool_max": 8}, {"pool_div": 16, "pool_max": 2048}, {"trace_wps": 4},
+                 {"trace_wps": 6}, {"trace_wps": 8}, {"lds_nodes": 0}, {"lds_nodes": 7}):
+        s2 = bunny_small.upload(hip)
+        for k, v in opts.items():
+            s2.set_option(k, v)
+        assert np.array_equal(_bits(s2.render(p)), _bits(ref)), opts
+    with pytest.raises(trace.TraceError, match="unknown option"):
+        sg.set_option("no_such_knob", 1)
+
+
+def test_deep_skewed_tree_uses_many_stack_rows(hip, oracle):
+    """A median-split tree with leaf size 1 over a thin strip of triangles: depth 12+, every ray
+    walks long chains; exercises the LDS stack rows and the leaf encoding with n = 1."""
+    rng = np.random.default_rng(4)
+    n = 3000
+    T = np.zeros((n, 36), np.float32)
+    c = np.stack([np.linspace(-3, 3, n), rng.uniform(-0.2, 0.2, n), rng.uniform(-0.2, 0.2, n)], 1)
+    P = (c[:, None, :] + rng.uniform(-0.05, 0.05, (n, 3, 3))).astype(np.float32)
+    T[:, :9] = P.reshape(n, 9)
+    T[:, 9:18] = np.tile([0, 0, 1], 3)
+    T[:, 18:36] = S.Material.disney(baseColor=(0.8, 0.6, 0.4)).to18()
+    hs = S.HostScene()
+    hs.addTriangles(T)
+    hs.buildBVH(1)
+    tri, nodes = hs.encode()
+    sg, so = hip.scene_create(tri, nodes), oracle.scene_create(tri, nodes)
+    assert sg.stats()["depth"] >= 12 and sg.stats()["max_leaf"] == 1
+    hdr = scenes.synthetic_hdr(64, 32)
+    sg.set_env(hdr, None, 1)
+    so.set_env(hdr, None, 1)
+    eye, cam = S.camera(30, 5, 6)
+    p = trace.make_params(160, 96, eye, cam, 50, 3, spp=2)
+    assert np.array_equal(_bits(sg.render(p)), _bits(so.render(p)))
+    from test_oracle import random_rays
+    rays = random_rays(20000, 9) * np.array([2, 0.1, 0.1, 1, 1, 1], np.float32)
+    tg, dg = sg.query_hits(rays)
+    to, do = so.query_hits(rays)
+    assert np.array_equal(tg, to) and np.array_equal(_bits(dg), _bits(do))
