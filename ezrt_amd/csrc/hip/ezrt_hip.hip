@@ -61,11 +61,12 @@ struct Tuning {
   int megakernel = 0;      // 1: v1 one-lane-per-path kernel instead of the streaming pipeline
   int packet = 0;          // 1: packet traversal for primary rays (slower on C2: 1.48+0.61 ms vs 1.55 ms)
   int packet_budget = 48;  // steps after which a packet hands its rays to the per-lane kernel
-  int leaf_threshold = 4;  // lanes waiting at a leaf that trigger the triangle phase
+  int leaf_threshold = 24; // lanes waiting at a leaf that trigger the triangle phase
   int pool_div = 1;        // ray-index pool = clamp(n_rays / (n_waves * pool_div), 8, pool_max)
   int pool_max = 256;
   int trace_wps = 5;       // traceq_kernel register budget: waves per SIMD (4, 5, 6 or 8)
   int lds_nodes = 1 << 20; // cap on top-of-tree records staged in LDS
+  int steal = 1;           // intra-wave work stealing in traceq_kernel (+ a redo launch for exact ties)
   int debug_stages = 0;    // print per-stage queue sizes (synchronises)
 };
 struct TuningName {
@@ -76,7 +77,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel}, {"packet", &T
                               {"packet_budget", &Tuning::packet_budget}, {"leaf_threshold", &Tuning::leaf_threshold},
                               {"pool_div", &Tuning::pool_div}, {"pool_max", &Tuning::pool_max},
                               {"trace_wps", &Tuning::trace_wps}, {"lds_nodes", &Tuning::lds_nodes},
-                              {"debug_stages", &Tuning::debug_stages}};
+                              {"steal", &Tuning::steal}, {"debug_stages", &Tuning::debug_stages}};
 Tuning tuning_from_env() {
   Tuning t;
   for (const TuningName& k : kTuning) {
@@ -112,7 +113,8 @@ struct EzrtScene {
   // wavefront queues (ping-pong)
   DevBuf<float4> rq_o[2], rq_d[2];
   DevBuf<float4> st[2][5];
-  DevBuf<int2> hits;
+  DevBuf<int2> hits2[2];        // hit records, ping-pong with the ray queues
+  DevBuf<uint32_t> redo_flag;   // per ray slot: already on the redo list
   DevBuf<uint32_t> qcounts; // [0..63] path counts per stage, [64..99] trace queue heads, [100..115] debug,
                             // [120] redo count, [121] redo queue head
   DevBuf<uint32_t> redo_slots;
@@ -271,9 +273,17 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
     HIP_TRY(s->rq_d[k].ensure(n_rays_max));
     for (int j = 0; j < (mis ? 5 : 4); j++) HIP_TRY(s->st[k][j].ensure(n_slots));
   }
-  HIP_TRY(s->hits.ensure(n_rays_max));
-  HIP_TRY(s->qcounts.ensure(128));
-  HIP_TRY(hipMemsetAsync(s->qcounts.p, 0, 128 * sizeof(uint32_t), st));
+  HIP_TRY(s->hits2[0].ensure(n_rays_max));
+  HIP_TRY(s->hits2[1].ensure(n_rays_max));
+  HIP_TRY(s->redo_slots.ensure(n_rays_max));
+  if (s->redo_flag.n < n_rays_max) { // zeroed once; every entry set is cleared again by the redo launch
+    HIP_TRY(s->redo_flag.ensure(n_rays_max));
+    HIP_TRY(hipMemsetAsync(s->redo_flag.p, 0, n_rays_max * sizeof(uint32_t), st));
+  }
+  // [0..63] paths per stage, [64..99] queue heads, [100..119] debug, [120,121] packet redo,
+  // [128..] redo counts per stage, [192..] redo queue heads per stage
+  HIP_TRY(s->qcounts.ensure(256));
+  HIP_TRY(hipMemsetAsync(s->qcounts.p, 0, 256 * sizeof(uint32_t), st));
   if (!s->num_cus) {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -305,7 +315,8 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
   a.n_slots = (uint32_t)n_slots;
   a.samples = s->samples.p;
   a.counters = s->counters.p;
-  a.hits = s->hits.p;
+  a.hits = s->hits2[1].p;
+  a.hits_out = reinterpret_cast<unsigned long long*>(s->hits2[0].p);
   // raygen -> queue 0
   a.rq_in = queue(1);
   a.rq_out = queue(0);
@@ -334,7 +345,7 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
   if (lds_nodes > s->n_inner) lds_nodes = s->n_inner;
   if (lds_nodes > lds_nodes_max) lds_nodes = lds_nodes_max;
   const size_t lds_t = lds_fixed + (size_t)lds_nodes * 80;
-  const unsigned trace_grid = (unsigned)(s->num_cus * blocks_per_cu);
+  const unsigned trace_grid_full = (unsigned)(s->num_cus * blocks_per_cu);
   unsigned shade_grid = (unsigned)((n_slots + SHADE_BLOCK - 1) / SHADE_BLOCK);
   if (shade_grid > 2048u) shade_grid = 2048u;
 
@@ -343,7 +354,7 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
     TraceQArgs t;
     t.sc = a.sc;
     t.rq = queue(in);
-    t.hits = s->hits.p;
+    t.hits = s->hits2[in].p;
     t.n_paths = s->qcounts.p + b;
     t.rays_per_path = (mis && b > 0) ? 2u : 1u;
     t.head = s->qcounts.p + 64 + b;
@@ -355,18 +366,31 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
     t.lds_nodes = lds_nodes;
     t.dbg = debug_stages ? (s->qcounts.p + 100 + 4 * (b & 3)) : nullptr;
     t.slot_map = nullptr;
+    t.steal = tu.steal ? 1u : 0u;
+    t.count_rays = 1u;
+    t.redo_count = s->qcounts.p + 128 + b;
+    t.redo_slots = s->redo_slots.p;
+    t.redo_flag = s->redo_flag.p;
+    auto launch_traceq = [&](const TraceQArgs& q, bool small = false) {
+      const unsigned trace_grid = small ? 64u : trace_grid_full; // redo lists are (nearly) empty
+      if (full) hipLaunchKernelGGL((traceq_kernel<true, 6>), dim3(trace_grid), dim3(BLOCK), lds_t, st, q);
+      else if (trace_wps == 8) hipLaunchKernelGGL((traceq_kernel<false, 8>), dim3(trace_grid), dim3(BLOCK), lds_t, st, q);
+      else if (trace_wps == 6) hipLaunchKernelGGL((traceq_kernel<false, 6>), dim3(trace_grid), dim3(BLOCK), lds_t, st, q);
+      else if (trace_wps == 4) hipLaunchKernelGGL((traceq_kernel<false, 4>), dim3(trace_grid), dim3(BLOCK), lds_t, st, q);
+      else hipLaunchKernelGGL((traceq_kernel<false, 5>), dim3(trace_grid), dim3(BLOCK), lds_t, st, q);
+      s->n_trace_launches++;
+    };
     int e = s->n_trace_events;
     if (e < MAX_TRACE_EVENTS) HIP_TRY(hipEventRecord(s->ev_trace[e][0], st));
     if (b == 0 && !full && use_packet) {
-      // primary rays: packet traversal (one wave = one 8x8 tile); rays with an exact distance tie are
-      // put on a redo list, which the per-lane kernel below then traces in the reference's order
-      HIP_TRY(s->redo_slots.ensure(n_slots));
+      // primary rays: packet traversal (one wave = one 8x8 tile); rays with an exact distance tie and
+      // rays of over-budget packets go to a redo list that the per-lane kernel traces in reference order
       TracePkArgs k;
       k.tri_geom = s->tri_geom.p;
       k.inner = s->inner.p;
       k.root_ref = s->root_ref;
       k.rq = queue(in);
-      k.hits = s->hits.p;
+      k.hits = s->hits2[in].p;
       k.n_rays = (uint32_t)n_slots;
       k.counters = s->counters.p;
       k.redo_count = s->qcounts.p + 120;
@@ -378,21 +402,34 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
       unsigned pk_grid = (unsigned)(s->num_cus * 7); // 66 VGPRs: 7 waves/SIMD = 7 workgroups of 4 waves per CU
       if ((size_t)pk_grid * BLOCK > n_slots) pk_grid = (unsigned)((n_slots + BLOCK - 1) / BLOCK);
       hipLaunchKernelGGL(tracepk_kernel, dim3(pk_grid), dim3(BLOCK), lds_pk, st, k);
+      s->n_trace_launches++;
       t.slot_map = s->redo_slots.p;
       t.n_paths = s->qcounts.p + 120;
       t.head = s->qcounts.p + 121;
-      s->n_trace_launches++;
+      t.rays_per_path = 1u;
+      t.steal = 0u;
+      t.redo_flag = nullptr;
+      launch_traceq(t);
+    } else {
+      launch_traceq(t);
+      if (t.steal) { // rays that met an exact distance tie (normally none): reference order, plain stores
+        TraceQArgs r = t;
+        r.steal = 0u;
+        r.count_rays = 0u;
+        r.slot_map = s->redo_slots.p;
+        r.n_paths = s->qcounts.p + 128 + b;
+        r.rays_per_path = 1u;
+        r.head = s->qcounts.p + 192 + b;
+        r.dbg = nullptr;
+        launch_traceq(r, true);
+      }
     }
-    if (full) hipLaunchKernelGGL((traceq_kernel<true, 6>), dim3(trace_grid), dim3(BLOCK), lds_t, st, t);
-    else if (trace_wps == 8) hipLaunchKernelGGL((traceq_kernel<false, 8>), dim3(trace_grid), dim3(BLOCK), lds_t, st, t);
-    else if (trace_wps == 5) hipLaunchKernelGGL((traceq_kernel<false, 5>), dim3(trace_grid), dim3(BLOCK), lds_t, st, t);
-    else if (trace_wps == 4) hipLaunchKernelGGL((traceq_kernel<false, 4>), dim3(trace_grid), dim3(BLOCK), lds_t, st, t);
-    else hipLaunchKernelGGL((traceq_kernel<false, 6>), dim3(trace_grid), dim3(BLOCK), lds_t, st, t);
     if (e < MAX_TRACE_EVENTS) {
       HIP_TRY(hipEventRecord(s->ev_trace[e][1], st));
       s->n_trace_events++;
     }
-    s->n_trace_launches++;
+    a.hits = s->hits2[in].p;
+    a.hits_out = reinterpret_cast<unsigned long long*>(s->hits2[out].p);
     a.rq_in = queue(in);
     a.rq_out = queue(out);
     a.st_in = state(in);

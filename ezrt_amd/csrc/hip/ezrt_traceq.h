@@ -40,7 +40,19 @@ struct TraceQArgs {
   int32_t lds_nodes;       // inner records [0, lds_nodes) staged in LDS (after stack + lane table)
   int32_t stack_entries;   // LDS stack rows (tree depth); the per-wave lane table follows them
   uint32_t* dbg;           // diagnostic (FULLCTR only): [0] max pops/ray [1] max tris/ray [2] max iterations/ray
-  const uint32_t* slot_map; // optional indirection: queue index -> ray slot (redo list of tracepk_kernel)
+  const uint32_t* slot_map; // optional indirection: queue index -> ray slot (a redo list)
+  // Work stealing (steal != 0): a lane with nothing left to fetch takes the OLDEST pending subtree of a
+  // busy lane of its wave and traverses it for that lane's ray.  hitBVH is unpruned, so subtrees are
+  // independent and the ray's result is the minimum over all of them: every contributor merges its
+  // {t, triangle} into hits[slot] with one 64-bit atomicMin (the record is reset to ~0 = "no hit yet"
+  // when the ray is first split; rays that are never split store their result plainly).  Order then
+  // only matters for EXACT ties in t; whoever sees one appends the ray to the redo list, which a
+  // second launch (steal = 0, reference order, plain stores) re-traces.  count_rays = 0 in that launch.
+  uint32_t steal;
+  uint32_t count_rays;
+  uint32_t* redo_count;
+  uint32_t* redo_slots;
+  uint32_t* redo_flag; // one word per ray slot: a ray is appended once (cleared again by the redo launch)
 };
 
 EZD uint32_t lane_rank(unsigned long long mask) { // number of set bits below this lane
@@ -54,6 +66,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
   const DevScene& sc = a.sc;
   const uint32_t n_rays = (*a.n_paths) * a.rays_per_path;
   const int lane = threadIdx.x & 63;
+  if (n_rays == 0) return; // (redo launches are normally empty)
   int* wsrc = lds_stack + a.stack_entries * BLOCK + (threadIdx.x >> 6) * 64;
   float4* lds_nodes = reinterpret_cast<float4*>(lds_stack + a.stack_entries * BLOCK + BLOCK);
   for (int k = threadIdx.x; k < a.lds_nodes * 4; k += BLOCK) lds_nodes[(k >> 2) * 5 + (k & 3)] = sc.inner[k];
@@ -75,10 +88,37 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
   f3 S = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
   float best_t = INF;
   int32_t best_tri = -1;
-  int sp = 0;
+  int sp = 0, sb = 0; // live stack entries are rows [sb, sp): the owner pops at sp, thieves take row sb
+  bool tie = false;    // two contributors published the same best distance for different triangles
+  bool shared = false; // this lane's ray has been split: other lanes hold subtrees of it (or this lane is a thief)
   uint32_t ref = 0;
   Counters ctr = {0, 0, 0, 0, 0, 0, 0};
   uint32_t ray_p0 = 0, ray_t0 = 0, ray_i0 = 0, iters = 0;
+  unsigned long long* hits64 = reinterpret_cast<unsigned long long*>(a.hits);
+
+  // end of this lane's (sub)traversal: publish {t, triangle}
+  auto finish = [&]() {
+    if (shared) { // several lanes contribute to this ray: merge with a 64-bit atomicMin
+      if (best_tri >= 0) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(best_t) << 32) | (uint32_t)best_tri;
+        const unsigned long long old = atomicMin(&hits64[slot], key);
+        if ((uint32_t)(old >> 32) == (uint32_t)(key >> 32) && (uint32_t)old != (uint32_t)key) tie = true;
+      }
+      if (tie && atomicExch(&a.redo_flag[slot], 1u) == 0u) a.redo_slots[atomicAdd(a.redo_count, 1u)] = slot; // rare
+    } else {
+      a.hits[slot] = make_int2(best_tri, __float_as_int(best_t));
+    }
+    work = false;
+    tie = false;
+    shared = false;
+    sp = 0;
+    sb = 0;
+    if (FULLCTR && a.dbg) {
+      atomicMax(a.dbg, ctr.pops - ray_p0);
+      atomicMax(a.dbg + 1, ctr.tris - ray_t0);
+      atomicMax(a.dbg + 2, iters - ray_i0);
+    }
+  };
 
   for (;;) {
     if (FULLCTR) iters++;
@@ -97,8 +137,9 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
           best_t = INF;
           best_tri = -1;
           sp = 0;
+          sb = 0;
           ref = sc.root_ref;
-          ctr.rays++;
+          ctr.rays += a.count_rays;
           if (FULLCTR) {
             ray_p0 = ctr.pops;
             ray_t0 = ctr.tris;
@@ -133,7 +174,11 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
           if (pool_next >= n_rays && pool_end >= n_rays) exhausted = true;
         }
         if (need && served && idx < n_rays) {
-          const uint32_t rs = a.slot_map ? a.slot_map[idx] : idx;
+          uint32_t rs = idx;
+          if (a.slot_map) {
+            rs = a.slot_map[idx];
+            if (a.redo_flag) a.redo_flag[rs] = 0u;
+          }
           nx_slot = rs;
           nx_o = a.rq.o[rs];
           nx_d = a.rq.d[rs];
@@ -142,6 +187,60 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
       }
     }
     if (!__ballot(work || nx_valid)) break;
+
+    // ---- work stealing: lanes with nothing left to fetch take the oldest pending subtree of a busy lane
+    if (a.steal) {
+      const bool idle = !work && !nx_valid;
+      const unsigned long long im = __ballot(idle);
+      if (im) {
+        const bool rich = work && (sp - sb) >= 1;
+        const unsigned long long vm = __ballot(rich);
+        if (vm) {
+          const int ni = (int)__popcll(im), nv = (int)__popcll(vm);
+          const int n = ni < nv ? ni : nv;
+          const int ir = (int)lane_rank(im), vr = (int)lane_rank(vm);
+          const bool victim = rich && vr < n, thief = idle && ir < n;
+          int give = 0;
+          if (victim) { // hand over the bottom row
+            wsrc[vr] = lane;
+            give = stack[sb * BLOCK];
+            sb++;
+            // first split of this ray: reset its record to "no hit yet" (~0).  The thieves' atomicMins
+            // are issued by this same wave, later in program order, to the same address: they reach
+            // the L2 after this atomic.
+            if (!shared) atomicExch(&hits64[slot], ~0ull);
+            shared = true;
+          }
+          __builtin_amdgcn_wave_barrier();
+          const int src = thief ? wsrc[ir] : lane;
+          const int got = __shfl(give, src, 64);
+          const uint32_t vslot = (uint32_t)__shfl((int)slot, src, 64);
+          const float vsx = __shfl(S.x, src, 64), vsy = __shfl(S.y, src, 64), vsz = __shfl(S.z, src, 64);
+          const float vdx = __shfl(d.x, src, 64), vdy = __shfl(d.y, src, 64), vdz = __shfl(d.z, src, 64);
+          const int vwild = __shfl((int)wild, src, 64);
+          if (thief) {
+            work = true;
+            shared = true;
+            slot = vslot;
+            S = mk(vsx, vsy, vsz);
+            d = mk(vdx, vdy, vdz);
+            inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            wild = vwild != 0;
+            best_t = INF;
+            best_tri = -1;
+            sp = 0;
+            sb = 0;
+            ref = (uint32_t)got;
+            if (FULLCTR) {
+              ray_p0 = ctr.pops;
+              ray_t0 = ctr.tris;
+              ray_i0 = iters;
+              ctr.pops++;
+            }
+          }
+        }
+      }
+    }
 
     // ---- inner step for every lane standing on an inner node (P5/fsh:277-302)
     const bool at_inner = work && !(ref & LEAF_BIT);
@@ -183,18 +282,12 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
       } else if (h1 || h2) {
         ref = h1 ? left : right;
         if (FULLCTR) ctr.pops++;
-      } else if (sp > 0) {
+      } else if (sp > sb) {
         sp--;
         ref = (uint32_t)stack[sp * BLOCK];
         if (FULLCTR) ctr.pops++;
       } else {
-        a.hits[slot] = make_int2(best_tri, __float_as_int(best_t));
-        work = false;
-        if (FULLCTR && a.dbg) {
-          atomicMax(a.dbg, ctr.pops - ray_p0);
-          atomicMax(a.dbg + 1, ctr.tris - ray_t0);
-          atomicMax(a.dbg + 2, iters - ray_i0);
-        }
+        finish();
       }
     }
 
@@ -265,18 +358,12 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
           }
         }
         if (at_leaf) {
-          if (sp > 0) {
+          if (sp > sb) {
             sp--;
             ref = (uint32_t)stack[sp * BLOCK];
             if (FULLCTR) ctr.pops++;
           } else {
-            a.hits[slot] = make_int2(best_tri, __float_as_int(best_t));
-            work = false;
-            if (FULLCTR && a.dbg) {
-              atomicMax(a.dbg, ctr.pops - ray_p0);
-              atomicMax(a.dbg + 1, ctr.tris - ray_t0);
-              atomicMax(a.dbg + 2, iters - ray_i0);
-            }
+            finish();
           }
         }
       }

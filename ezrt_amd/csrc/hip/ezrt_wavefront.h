@@ -48,6 +48,7 @@ struct WfArgs {
   RayQueue rq_in, rq_out;
   PathState st_in, st_out;
   const int2* hits;        // per ray slot of rq_in: (tri, bits(t))
+  unsigned long long* hits_out; // hit records of rq_out's slots (ping-pong with `hits`; written by the trace)
   const uint32_t* n_in;    // paths in the input queue (device)
   uint32_t* n_out;         // paths in the output queue (device, atomically grown)
   int32_t bounce;          // the bounce this stage starts (0 = consumes the primary hits)
