@@ -183,7 +183,7 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-            "kernel": "ezd::traceq_kernel<false,6>",
+            "kernel": "ezd::traceq_kernel<false,5>",
             "alg_bytes_per_launch": int(bytes_trace // launches), "alg_bytes_per_ray": round(bytes_trace / c["rays"], 1),
             "launch_ms": round(ms_trace / launches, 4), "launches_per_step": launches,
             "counters_per_step": {k: c[k] for k in ("rays", "node_pops", "inner_pops", "tri_tests", "mat_fetch", "samples", "env_map", "env_cache")},
@@ -210,13 +210,25 @@ def main():
             t1 = time.perf_counter()
             so.render(trace.make_params(W, H, eye, cam, args.integrator, args.bounces, spp=n, frame0=1), img)
             dn = time.perf_counter() - t1
-            cr = so.counters()["rays"]
             gpu_img = final.detach().cpu().numpy()
-            out["cpu_baseline"] = {"value": round(cr / dn / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            linf = float(np.abs(gpu_img - img).max()) if n + 1 == args.spp else None
+            # many-core hosts finish the 64-spp frame in under a second: keep sampling further frames of the
+            # same workload (into a scratch image) until the sample is ~cpu_seconds of CPU work
+            n_total, d_total = n, dn
+            if dn < args.cpu_seconds and n + 1 == args.spp:
+                extra = int(min(8192, (args.cpu_seconds - dn) / max(dn / n, 1e-4)))
+                if extra > 0:
+                    t1 = time.perf_counter()
+                    so.render(trace.make_params(W, H, eye, cam, args.integrator, args.bounces, spp=extra, frame0=args.spp),
+                              img.copy())
+                    d_total += time.perf_counter() - t1
+                    n_total += extra
+            cr = so.counters()["rays"]
+            out["cpu_baseline"] = {"value": round(cr / d_total / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
                                    "sample": "frames 1..%d of the same %dx%d workload (%d rays, %.1f s), OpenMP over rows"
-                                             % (n, W, H, cr, dn)}
-            if n + 1 == args.spp:
-                out["cpu_baseline"]["linf_vs_gpu"] = float(np.abs(gpu_img - img).max())
+                                             % (n_total, W, H, cr, d_total)}
+            if linf is not None:
+                out["cpu_baseline"]["linf_vs_gpu"] = linf
 
     if rank == 0:
         if args.save_png:
