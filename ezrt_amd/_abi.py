@@ -83,6 +83,8 @@ HOST_ABI = {
     "ezrt_host_hdr_cache": (C.c_int, [c_float_p, C.c_int, C.c_int, c_float_p]),
     "ezrt_host_free": (None, [C.c_void_p]),
     "ezrt_host_camera": (C.c_int, [C.c_float, C.c_float, C.c_float, c_float_p, c_float_p]),
+    "ezrt_host_p2_query": (C.c_int, [c_float_p, C.c_int, C.c_int, C.c_int, c_float_p, C.c_int, C.c_int, c_float_p,
+                                     C.POINTER(C.c_int), c_float_p]),
     "ezrt_host_last_error": (C.c_char_p, []),
 }
 

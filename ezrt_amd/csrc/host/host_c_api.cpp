@@ -223,6 +223,40 @@ int ezrt_host_camera(float rot, float up, float r, float eye3[3], float cam16[16
   return 0;
 }
 
+int ezrt_host_p2_query(const float* tri9, int n_tri, int method, int leaf_n, const float* rays6, int n_rays,
+                       int use_bvh, float* tri_sorted9, int* hit_index, float* hit_t) {
+  if (!tri9 || n_tri <= 0 || (n_rays > 0 && (!rays6 || !hit_index || !hit_t))) return fail(-1, "bad argument");
+  if (method != 0 && method != 1) return fail(-1, "method must be 0 (median) or 1 (SAH)");
+  EZ_TRY
+  std::vector<p2::Triangle> tris;
+  tris.reserve((size_t)n_tri);
+  for (int i = 0; i < n_tri; i++) {
+    const float* p = tri9 + (size_t)i * 9;
+    tris.push_back(p2::Triangle(vec3(p[0], p[1], p[2]), vec3(p[3], p[4], p[5]), vec3(p[6], p[7], p[8])));
+  }
+  p2::BVHNode* root = method ? p2::buildBVHwithSAH(tris, 0, n_tri - 1, leaf_n) : p2::buildBVH(tris, 0, n_tri - 1, leaf_n);
+  if (tri_sorted9)
+    for (int i = 0; i < n_tri; i++) {
+      float* p = tri_sorted9 + (size_t)i * 9;
+      const p2::Triangle& t = tris[(size_t)i];
+      p[0] = t.p1.x; p[1] = t.p1.y; p[2] = t.p1.z;
+      p[3] = t.p2.x; p[4] = t.p2.y; p[5] = t.p2.z;
+      p[6] = t.p3.x; p[7] = t.p3.y; p[8] = t.p3.z;
+    }
+  for (int i = 0; i < n_rays; i++) {
+    const float* q = rays6 + (size_t)i * 6;
+    p2::Ray ray;
+    ray.startPoint = vec3(q[0], q[1], q[2]);
+    ray.direction = vec3(q[3], q[4], q[5]);
+    p2::HitResult res = use_bvh ? p2::hitBVH(ray, tris, root) : p2::hitTriangleArray(ray, tris, 0, n_tri - 1);
+    hit_index[i] = res.triangle ? (int)(res.triangle - tris.data()) : -1;
+    hit_t[i] = res.distance;
+  }
+  p2::freeBVH(root);
+  return 0;
+  EZ_CATCH
+}
+
 const char* ezrt_host_last_error(void) { return g_err.c_str(); }
 
 } // extern "C"

@@ -157,3 +157,19 @@ def camera(rotatAngle=0.0, upAngle=0.0, r=4.0):
     m = np.zeros(16, np.float32)
     _check(lib.ezrt_host_camera(float(rotatAngle), float(upAngle), float(r), _fp(eye), _fp(m)), lib)
     return eye, m
+
+
+def p2Query(tri9, rays, sah=True, leaf_n=8, use_bvh=True):
+    """Chapter 2's CPU query (ezrt::p2, P2/main.cpp:242-485): build the pointer tree over
+    `tri9` [n, 9], shoot `rays` [m, 6] through hitBVH (or hitTriangleArray over everything when
+    use_bvh is False).  Returns (sorted triangles [n, 9], hit index [m] into them or -1,
+    distance [m], INF = 114514 on a miss)."""
+    lib = _abi.load_host()
+    tri9 = np.ascontiguousarray(tri9, np.float32).reshape(-1, 9)
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    out = np.zeros_like(tri9)
+    idx = np.zeros(rays.shape[0], np.int32)
+    t = np.zeros(rays.shape[0], np.float32)
+    _check(lib.ezrt_host_p2_query(_fp(tri9), tri9.shape[0], int(bool(sah)), int(leaf_n), _fp(rays), rays.shape[0],
+                                  int(bool(use_bvh)), _fp(out), idx.ctypes.data_as(C.POINTER(C.c_int)), _fp(t)), lib)
+    return out, idx, t

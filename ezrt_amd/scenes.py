@@ -210,7 +210,59 @@ CONFIGS = {
     "C2": dict(width=512, height=512, spp=64, max_bounce=4, integrator=INTEGRATOR_P5_SOBOL, camera=(0, 0, 4)),
     "C3": dict(width=1024, height=1024, spp=128, max_bounce=4, integrator=INTEGRATOR_P4_DISNEY, camera=(0, 15, 8)),
     "C4": dict(width=1024, height=1024, spp=256, max_bounce=2, integrator=INTEGRATOR_P5_MIS, camera=(90, 10, 2)),
+    "C5": dict(width=2048, height=2048, spp=512, max_bounce=8, integrator=INTEGRATOR_P5_MIS, camera=(30, 25, 10)),
 }
+
+
+def _unit(seed, k):
+    """k-th deterministic float32 in [0,1) of instance `seed` (Wang hash, as the shader's RNG)."""
+    h = int(_hash_u32(np.array([seed * 9781 + k * 6271 + 1], np.uint32))[0])
+    return np.float32(h >> 8) / np.float32(16777216.0)
+
+
+def mega_scene(hdr="synthetic", leaf_n=8):
+    """C5: exactly 1 000 000 triangles -- 48 instances of the 20 480-face sphere (= the face count of
+    the reference's sphere2.obj) with per-instance transform and Disney parameters from
+    wang_hash(instance id), 3 Bunnies (14 904), and 1 028 two-triangle quads: a 32x32 tiled floor
+    plus 4 emissive panels."""
+    hs = S.HostScene()
+    sv, sf = mesh("sphere")
+    sv, sf = subdivide(sv, sf, 3)
+    c = sv.mean(axis=0, dtype=np.float32)
+    r = np.sqrt(((sv[:162] - c) ** 2).sum(1)).mean(dtype=np.float32)
+    dv = sv - c
+    ln = np.sqrt((dv * dv).sum(1, dtype=np.float32)).astype(np.float32)
+    sv = (c + dv * (r / ln)[:, None]).astype(np.float32)
+    stext = obj_text(sv, sf)
+    for i in range(48):
+        gx, gz = i % 8, i // 8
+        s = 0.55 + 0.5 * float(_unit(i, 0))
+        pos = (-5.6 + 1.6 * gx + 0.5 * (float(_unit(i, 1)) - 0.5), -1.4 + s * 0.5 + 1.5 * float(_unit(i, 2)) * (i % 3 == 0),
+               -4.0 + 1.6 * gz + 0.5 * (float(_unit(i, 3)) - 0.5))
+        m = S.Material.disney(baseColor=(0.3 + 0.7 * float(_unit(i, 4)), 0.3 + 0.7 * float(_unit(i, 5)),
+                                         0.3 + 0.7 * float(_unit(i, 6))),
+                              metallic=float(_unit(i, 7)), roughness=0.05 + 0.75 * float(_unit(i, 8)),
+                              clearcoat=float(_unit(i, 9)), subsurface=0.5 * float(_unit(i, 10)))
+        rot = (360.0 * float(_unit(i, 11)), 360.0 * float(_unit(i, 12)), 0.0)
+        hs.readObjText(stext, m, S.getTransformMatrix(rot, pos, (s, s, s)), True)
+    bv, bf = mesh("bunny")
+    btext = obj_text(bv, bf)
+    gold = S.Material.disney(roughness=0.5, specular=1.0, metallic=1.0, clearcoat=1.0, clearcoatGloss=0.0,
+                             baseColor=(1, 0.73, 0.25))
+    for k, (x, z, ry) in enumerate(((-2.0, 4.4, 20.0), (0.5, 4.8, -35.0), (3.0, 4.2, 140.0))):
+        hs.readObjText(btext, gold, S.getTransformMatrix((0, ry, 0), (x, -1.55, z), (1.4, 1.4, 1.4)), True)
+    quad = obj_text(np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], np.float32),
+                    np.array([[0, 2, 1], [0, 3, 2]], np.int32))
+    for i in range(1024):
+        tx, tz = i % 32, i // 32
+        shade = 0.55 + 0.25 * ((tx + tz) & 1)
+        m = S.Material.disney(baseColor=(shade, shade, shade), roughness=0.2 + 0.6 * float(_unit(1000 + i, 0)))
+        hs.readObjText(quad, m, S.getTransformMatrix((0, 0, 0), (-15.5 + tx, -1.4, -15.5 + tz), (1.0, 1.0, 1.0)), False)
+    for k, (x, z) in enumerate(((-4.0, -2.0), (4.0, -2.0), (-4.0, 3.0), (4.0, 3.0))):
+        m = S.Material.disney(baseColor=(1, 1, 1), emissive=(18.0, 16.0 - 2.0 * k, 10.0 + 2.0 * k))
+        hs.readObjText(quad, m, S.getTransformMatrix((180, 0, 0), (x, 3.2, z), (1.5, 1.0, 1.5)), False)
+    h = synthetic_hdr() if isinstance(hdr, str) and hdr == "synthetic" else hdr
+    return _finish("mega_1m", hs, leaf_n, h, True, FILTER_BILINEAR)
 
 
 def disney_grid_scene(subdiv=3, hdr="synthetic", leaf_n=8):

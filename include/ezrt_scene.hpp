@@ -147,6 +147,54 @@ struct Camera {
 };
 Camera cameraFromAngles(float rotatAngleDeg, float upAngleDeg, float r);
 
+// ---------------------------------------------------------------------------
+// Chapter 2's CPU query API on a pointer tree (P2/main.cpp), kept for callers
+// that still use it.  Same names and argument meaning; the arithmetic is the
+// fp32 contract of DESIGN.md section 2, so distances are bit-identical to the
+// GPU trace's.
+//
+//   struct BVHNode{left,right,n,index,AA,BB}                   P2/main.cpp:28-34
+//   struct Triangle{p1,p2,p3,center}                           P2/main.cpp:36-43
+//   struct HitResult{Triangle* triangle = NULL; distance=INF}  P2/main.cpp:58-61
+//   BVHNode* buildBVH / buildBVHwithSAH(triangles, l, r, n)    P2/main.cpp:242-294, 297-423
+//   float hitTriangle(Triangle*, Ray)  (t or INF)              P2/main.cpp:212-238
+//   float hitAABB(Ray, AA, BB)                                 P2/main.cpp:449-463
+//   HitResult hitTriangleArray(ray, triangles, l, r)           P2/main.cpp:436-446
+//   HitResult hitBVH(ray, triangles, root)                     P2/main.cpp:466-485
+//
+// Deliberate difference: a leaf scans [index, index+n-1] as chapters 3-5 do
+// (P3/fsh:334-337); P2/main.cpp:471 passes (n, n+index-1), which only works
+// on its demo by accident.  The tree is owned by the caller:
+// release it with freeBVH (the reference leaks it).
+namespace p2 {
+constexpr float INF = 114514.0f;
+struct Triangle {
+  vec3 p1, p2, p3;
+  vec3 center;
+  Triangle(vec3 a, vec3 b, vec3 c);
+};
+struct BVHNode {
+  BVHNode* left = nullptr;
+  BVHNode* right = nullptr;
+  int n = 0, index = 0;
+  vec3 AA, BB;
+};
+struct Ray {
+  vec3 startPoint, direction;
+};
+struct HitResult {
+  Triangle* triangle = nullptr;
+  float distance = INF;
+};
+BVHNode* buildBVH(std::vector<Triangle>& triangles, int l, int r, int n);
+BVHNode* buildBVHwithSAH(std::vector<Triangle>& triangles, int l, int r, int n);
+void freeBVH(BVHNode* root);
+float hitTriangle(Triangle* triangle, Ray ray);
+float hitAABB(Ray r, vec3 AA, vec3 BB);
+HitResult hitTriangleArray(Ray ray, std::vector<Triangle>& triangles, int l, int r);
+HitResult hitBVH(Ray ray, std::vector<Triangle>& triangles, BVHNode* root);
+} // namespace p2
+
 } // namespace ezrt
 
 #endif

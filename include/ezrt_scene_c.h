@@ -57,6 +57,14 @@ void ezrt_host_free(void* p);
 /* eye + cameraRotate from (rotatAngle, upAngle, r) (P3/main.cpp:607-610) */
 int ezrt_host_camera(float rotat_angle_deg, float up_angle_deg, float r, float eye3[3], float camera_rotate16[16]);
 
+/* Chapter 2's CPU query (ezrt::p2 in ezrt_scene.hpp; P2/main.cpp:242-485) in one call:
+ * triangles as 9 floats (p1,p2,p3) -> buildBVH (method 0) / buildBVHwithSAH (1) with leaf size
+ * leaf_n -> per ray (origin3, direction3) hitBVH (use_bvh 1) or hitTriangleArray over everything (0).
+ * hit_index = index into the builder-sorted triangle array (returned in tri_sorted9 when not NULL)
+ * or -1; hit_t = distance or INF = 114514. */
+int ezrt_host_p2_query(const float* tri9, int n_tri, int method, int leaf_n, const float* rays6, int n_rays,
+                       int use_bvh, float* tri_sorted9, int* hit_index, float* hit_t);
+
 const char* ezrt_host_last_error(void);
 
 #ifdef __cplusplus

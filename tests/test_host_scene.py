@@ -236,3 +236,62 @@ def test_synthetic_hdr_is_deterministic():
 
 
 FULL_HDR_XOR = 8264391
+
+
+def _probe_rays(n, seed):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-3, 3, (n, 3))
+    tgt = rng.uniform(-1, 1, (n, 3))
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.concatenate([o, d], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("sah", [True, False])
+def test_p2_pointer_tree_query_equals_brute_force_and_the_oracle(oracle, bunny_small, sah):
+    """Chapter 2's acceptance check (P2/main.cpp:581-588: hitBVH == hitTriangleArray over the whole
+    array) on the host pointer-tree API, and the same distances, bit for bit, as the trace oracle."""
+    tri9 = bunny_small.tri[:, :9]
+    rays = _probe_rays(3000, 5)
+    tris, ib, tb = S.p2Query(tri9, rays, sah=sah, use_bvh=True)
+    _, ia, ta = S.p2Query(tri9, rays, sah=sah, use_bvh=False)
+    assert np.array_equal(tb.view(np.uint32), ta.view(np.uint32))
+    assert (ib >= 0).sum() > 500
+    assert np.array_equal(np.sort(tris.view(np.uint32), axis=0), np.sort(tri9.view(np.uint32), axis=0))
+    so = bunny_small.upload(oracle)
+    to_tri, to_t = so.query_hits(rays)
+    hit = to_tri >= 0
+    assert np.array_equal(hit, ib >= 0)
+    assert np.array_equal(tb[hit].view(np.uint32), to_t[hit].view(np.uint32))
+    assert np.all(tb[~hit] == np.float32(114514.0))
+    same = np.all(tris[ib[hit]] == tri9[to_tri[hit]], axis=1)      # identical triangle unless an exact tie in t
+    assert same.mean() > 0.99
+
+
+def test_c5_scene_has_exactly_a_million_triangles_and_hits_the_sah_cap():
+    c5 = scenes.mega_scene()
+    assert c5.tri.shape == (1_000_000, 36)
+    st = c5.build_stats
+    assert st["inf_cap_nodes"] > 0 and st["max_depth"] <= 150
+    n = c5.nodes[1:, 3].astype(np.int64)              # leafInfo.x = n
+    assert n[n > 0].sum() == 1_000_000 and n.max() <= 8
+
+
+def test_png_and_pfm_writers(tmp_path):
+    import zlib
+    from ezrt_amd import imageio
+    rng = np.random.default_rng(3)
+    img = rng.uniform(0, 2, (5, 7, 4)).astype(np.float32)
+    imageio.write_pfm(tmp_path / "a.pfm", img)
+    assert np.array_equal(imageio.read_pfm(tmp_path / "a.pfm"), img[..., :3])
+    q = imageio.quantize_p1(img[..., :3])
+    assert q.dtype == np.uint8 and q.max() == 255 and q[img[..., :3] < 1].max() < 255
+    imageio.write_png(tmp_path / "a.png", q)
+    raw = open(tmp_path / "a.png", "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n" and raw[12:16] == b"IHDR"
+    w, h = struct.unpack(">II", raw[16:24])
+    assert (w, h) == (7, 5)
+    i = raw.index(b"IDAT")
+    n = struct.unpack(">I", raw[i - 4:i])[0]
+    rows = np.frombuffer(zlib.decompress(raw[i + 4:i + 4 + n]), np.uint8).reshape(5, 1 + 7 * 3)
+    assert np.array_equal(rows[:, 1:].reshape(5, 7, 3), q[::-1])     # top row first
