@@ -17,7 +17,7 @@ HIP_DEPS = $(wildcard ezrt_amd/csrc/hip/*.h) $(wildcard ezrt_amd/csrc/hip/*.hip)
 # bit-identical between x86 and gfx950 (include/ezrt_detmath.h).
 HOST_FLAGS = -O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-math-errno -Wall -Wextra -Iinclude
 HIP_FLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math \
-            -fno-gpu-flush-denormals-to-zero -Wall -Wno-unused-function -Iinclude -Iezrt_amd/csrc/hip
+            -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize -Wall -Wno-unused-function -Iinclude -Iezrt_amd/csrc/hip
 
 all: host hip oracle
 

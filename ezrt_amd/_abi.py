@@ -114,7 +114,7 @@ def load_hip():
     is missing this raises."""
     global _hip
     if _hip is None:
-        path = os.path.join(LIB_DIR, "libezrt_hip.so")
+        path = os.environ.get("EZRT_HIP_LIB") or os.path.join(LIB_DIR, "libezrt_hip.so")  # override: A/B builds
         if not os.path.exists(path):
             raise RuntimeError(
                 "ezrt_amd: %s is missing -- build it with `make hip` (or __graft_entry__.build()); "

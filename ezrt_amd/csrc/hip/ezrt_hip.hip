@@ -3,6 +3,7 @@
 // re-lays the scene out for the GPU, and launches; there is no CPU compute path.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -115,6 +116,7 @@ struct EzrtScene {
   DevBuf<float4> st[2][5];
   DevBuf<int2> hits2[2];        // hit records, ping-pong with the ray queues
   DevBuf<uint32_t> redo_flag;   // per ray slot: already on the redo list
+  DevBuf<unsigned long long> wave_log; // debug_stages=2 only
   DevBuf<uint32_t> qcounts; // [0..63] path counts per stage, [64..99] trace queue heads, [100..115] debug,
                             // [120] redo count, [121] redo queue head
   DevBuf<uint32_t> redo_slots;
@@ -371,6 +373,12 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
     t.redo_count = s->qcounts.p + 128 + b;
     t.redo_slots = s->redo_slots.p;
     t.redo_flag = s->redo_flag.p;
+    t.wave_log = nullptr;
+    if (debug_stages >= 2) {
+      HIP_TRY(s->wave_log.ensure((size_t)trace_grid_full * (BLOCK / 64) * 4));
+      HIP_TRY(hipMemsetAsync(s->wave_log.p, 0, (size_t)trace_grid_full * (BLOCK / 64) * 4 * sizeof(unsigned long long), st));
+      t.wave_log = s->wave_log.p;
+    }
     auto launch_traceq = [&](const TraceQArgs& q, bool small = false) {
       const unsigned trace_grid = small ? 64u : trace_grid_full; // redo lists are (nearly) empty
       if (full) hipLaunchKernelGGL((traceq_kernel<true, 6>), dim3(trace_grid), dim3(BLOCK), lds_t, st, q);
@@ -421,6 +429,7 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
         r.rays_per_path = 1u;
         r.head = s->qcounts.p + 192 + b;
         r.dbg = nullptr;
+        r.wave_log = nullptr;
         launch_traceq(r, true);
       }
     }
@@ -448,6 +457,32 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
         uint32_t pk[3] = {0, 0, 0};
         HIP_TRY(hipMemcpy(pk, s->qcounts.p + 116, sizeof pk, hipMemcpyDeviceToHost));
         fprintf(stderr, "[ezrt] packet stage: wave inner steps %u, wave triangle steps %u, max steps of one wave %u\n", pk[0], pk[1], pk[2]);
+      }
+      if (debug_stages >= 2 && t.wave_log) { // per-wave life times of this stage's traceq launch
+        const size_t nw = (size_t)trace_grid_full * (BLOCK / 64);
+        std::vector<unsigned long long> w(nw * 4);
+        HIP_TRY(hipMemcpy(w.data(), s->wave_log.p, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (size_t i = 0; i < nw; i++)
+          if (w[i * 4] && w[i * 4] < t0) t0 = w[i * 4];
+        std::vector<double> endt, life, its, rays, startt;
+        for (size_t i = 0; i < nw; i++)
+          if (w[i * 4]) {
+            startt.push_back((double)(w[i * 4] - t0) * 0.01);
+            endt.push_back((double)(w[i * 4 + 1] - t0) * 0.01);
+            life.push_back((double)(w[i * 4 + 1] - w[i * 4]) * 0.01);
+            its.push_back((double)w[i * 4 + 2]);
+            rays.push_back((double)w[i * 4 + 3]);
+          }
+        auto pct = [](std::vector<double>& v, double q) {
+          if (v.empty()) return 0.0;
+          std::sort(v.begin(), v.end());
+          return v[(size_t)(q * (double)(v.size() - 1))];
+        };
+        fprintf(stderr, "[ezrt]   waves %zu | start us p50 %.1f max %.1f | end us p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f | life us p50 %.1f max %.1f | iters p50 %.0f p99 %.0f max %.0f | rays p50 %.0f max %.0f\n",
+                endt.size(), pct(startt, 0.5), pct(startt, 1.0), pct(endt, 0.1), pct(endt, 0.5), pct(endt, 0.9), pct(endt, 0.99),
+                pct(endt, 1.0), pct(life, 0.5), pct(life, 1.0), pct(its, 0.5), pct(its, 0.99), pct(its, 1.0), pct(rays, 0.5),
+                pct(rays, 1.0));
       }
       uint32_t dbg[3] = {0, 0, 0};
       HIP_TRY(hipMemcpy(dbg, s->qcounts.p + 100 + 4 * (b & 3), sizeof dbg, hipMemcpyDeviceToHost));

@@ -53,6 +53,7 @@ struct TraceQArgs {
   uint32_t* redo_count;
   uint32_t* redo_slots;
   uint32_t* redo_flag; // one word per ray slot: a ray is appended once (cleared again by the redo launch)
+  unsigned long long* wave_log; // diagnostic (debug_stages=2): per wave {start, end (100 MHz ticks), iterations, rays}
 };
 
 EZD uint32_t lane_rank(unsigned long long mask) { // number of set bits below this lane
@@ -73,9 +74,18 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
   __syncthreads();
 
   const uint32_t n_waves = gridDim.x * (BLOCK / 64);
-  uint32_t pool_size = n_rays / (n_waves * a.pool_div);
+  // Queue indices are handed out in pools of `pool_size`.  The first pool of every wave is static
+  // (wave w owns [w * pool_size, (w + 1) * pool_size)): no atomic at all for queues of up to
+  // n_waves * pool_max rays -- 5120 waves bumping one counter would cost ~60 us per round, the whole
+  // budget of a late bounce (one word sustains ~88 atomics/us chip-wide).  Indices beyond the static
+  // region are reserved dynamically, one atomic per pool.  (Smaller pools for the queue's last
+  // stretch, and eight interleaved counters with guided pool sizes, were tried: no gain -- the
+  // launch's tail is made of waves that drew an expensive pool well before the end.)
+  uint32_t pool_size = (n_rays + n_waves * a.pool_div - 1) / (n_waves * a.pool_div);
   pool_size = pool_size > a.pool_max ? a.pool_max : (pool_size < TRACE_POOL_MIN ? TRACE_POOL_MIN : pool_size);
-  uint32_t pool_next = 0, pool_end = 0; // wave-uniform pool of reserved ray indices
+  const uint32_t static_total = n_waves * pool_size;
+  uint32_t pool_next = (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * pool_size; // wave-uniform pool of ray indices
+  uint32_t pool_end = pool_next + pool_size;
   bool exhausted = false;               // wave-uniform: nothing left to reserve
 
   bool nx_valid = false; // prefetched next ray of this lane
@@ -120,8 +130,11 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
     }
   };
 
+  const unsigned long long t_start = a.wave_log ? wall_clock64() : 0ull;
+  uint32_t wave_iters = 0;
   for (;;) {
     if (FULLCTR) iters++;
+    wave_iters++;
     // ---- refill: lanes without work adopt their prefetched ray, then prefetch another
     const bool want = !work;
     if (__ballot(want)) {
@@ -156,9 +169,11 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
         uint32_t idx;
         bool served;
         if (pool_end - pool_next < cnt) { // wave-uniform: top the pool up with one atomic
-          uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(a.head, pool_size);
-          base = __shfl(base, 0, 64);
+          uint32_t base = n_rays; // (nothing beyond the static region: done)
+          if (static_total < n_rays) {
+            if (lane == 0) base = atomicAdd(a.head, pool_size);
+            base = static_total + __shfl(base, 0, 64);
+          }
           const uint32_t left = pool_end - pool_next; // hand out the old pool's rest first
           uint32_t take = cnt - left;
           if (take > pool_size) take = pool_size;
@@ -372,6 +387,13 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
 
   const unsigned long long rr = wave_sum(ctr.rays);
   if (lane == 0 && rr) atomicAdd(&a.counters[EZRT_CTR_RAYS], rr);
+  if (a.wave_log && lane == 0) {
+    unsigned long long* w = a.wave_log + (size_t)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 4;
+    w[0] = t_start;
+    w[1] = wall_clock64();
+    w[2] = wave_iters;
+    w[3] = rr;
+  }
   if (FULLCTR) {
     const unsigned long long v1 = wave_sum(ctr.pops), v2 = wave_sum(ctr.inner), v3 = wave_sum(ctr.tris),
                              v4 = wave_sum(ctr.mats);
