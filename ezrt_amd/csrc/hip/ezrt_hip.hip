@@ -67,6 +67,7 @@ struct Tuning {
   int pool_max = 256;
   int trace_wps = 5;       // traceq_kernel register budget: waves per SIMD (4, 5, 6 or 8)
   int lds_nodes = 1 << 20; // cap on top-of-tree records staged in LDS
+  int scatter = 1;         // primary rays enter the queue in a scattered 8x8 sub-block order (balances pools)
   int steal = 1;           // intra-wave work stealing in traceq_kernel (+ a redo launch for exact ties)
   int debug_stages = 0;    // print per-stage queue sizes (synchronises)
 };
@@ -78,7 +79,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel}, {"packet", &T
                               {"packet_budget", &Tuning::packet_budget}, {"leaf_threshold", &Tuning::leaf_threshold},
                               {"pool_div", &Tuning::pool_div}, {"pool_max", &Tuning::pool_max},
                               {"trace_wps", &Tuning::trace_wps}, {"lds_nodes", &Tuning::lds_nodes},
-                              {"steal", &Tuning::steal}, {"debug_stages", &Tuning::debug_stages}};
+                              {"steal", &Tuning::steal}, {"scatter", &Tuning::scatter}, {"debug_stages", &Tuning::debug_stages}};
 Tuning tuning_from_env() {
   Tuning t;
   for (const TuningName& k : kTuning) {
@@ -117,6 +118,7 @@ struct EzrtScene {
   DevBuf<int2> hits2[2];        // hit records, ping-pong with the ray queues
   DevBuf<uint32_t> redo_flag;   // per ray slot: already on the redo list
   DevBuf<unsigned long long> wave_log; // debug_stages=2 only
+  DevBuf<float> sobol_tab;  // [frames of the chunk][8]
   DevBuf<uint32_t> qcounts; // [0..63] path counts per stage, [64..99] trace queue heads, [100..115] debug,
                             // [120] redo count, [121] redo queue head
   DevBuf<uint32_t> redo_slots;
@@ -327,6 +329,25 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
   a.n_in = s->qcounts.p;
   a.n_out = s->qcounts.p;
   a.bounce = 0;
+  a.scatter = 1u;
+  if (s->tune.scatter) { // multiplier near 0.618 * n_sub, coprime to n_sub
+    const uint32_t n_sub = (uint32_t)nb * 4u;
+    auto gcd = [](uint32_t x, uint32_t y) {
+      while (y) {
+        const uint32_t t = x % y;
+        x = y;
+        y = t;
+      }
+      return x;
+    };
+    uint32_t m = (uint32_t)((double)n_sub * 0.6180339887);
+    if (m < 1u) m = 1u;
+    while (gcd(m, n_sub) != 1u) m++;
+    a.scatter = m % n_sub ? m % n_sub : 1u;
+  }
+  HIP_TRY(s->sobol_tab.ensure((size_t)nf * 8));
+  a.sobol_tab = s->sobol_tab.p;
+  hipLaunchKernelGGL(sobol_kernel, dim3((unsigned)((nf * 8 + 255) / 256)), dim3(256), 0, st, frame_first + 1u, (int)nf, 8, s->sobol_tab.p);
   hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((n_slots + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, a);
 
   const size_t lds = stack_lds_bytes(s);
@@ -359,6 +380,10 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
     t.hits = s->hits2[in].p;
     t.n_paths = s->qcounts.p + b;
     t.rays_per_path = (mis && b > 0) ? 2u : 1u;
+    t.const_origin = b == 0 ? 1u : 0u;
+    t.origin[0] = p->eye[0];
+    t.origin[1] = p->eye[1];
+    t.origin[2] = p->eye[2];
     t.head = s->qcounts.p + 64 + b;
     t.counters = s->counters.p;
     t.leaf_threshold = leaf_thr;
@@ -405,6 +430,9 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
       k.redo_slots = s->redo_slots.p;
       k.stack_entries = s->depth + 1;
       k.budget = packet_budget;
+      k.origin[0] = p->eye[0];
+      k.origin[1] = p->eye[1];
+      k.origin[2] = p->eye[2];
       k.dbg = debug_stages ? (s->qcounts.p + 116) : nullptr;
       const size_t lds_pk = (size_t)(BLOCK / 64) * k.stack_entries * 3 * sizeof(int);
       unsigned pk_grid = (unsigned)(s->num_cus * 7); // 66 VGPRs: 7 waves/SIMD = 7 workgroups of 4 waves per CU

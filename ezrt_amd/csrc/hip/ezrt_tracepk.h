@@ -29,6 +29,7 @@ struct TracePkArgs {
   uint32_t* redo_slots;        // their ray slots
   int32_t stack_entries;       // rows of the wave-uniform stack (tree depth + 1)
   int32_t budget;              // steps (nodes + triangles) after which a wave hands its rays to traceq_kernel
+  float origin[3];             // every primary ray starts here (rq.o is not stored for them)
   uint32_t* dbg;               // diagnostic: [0] wave inner steps [1] wave triangle steps [2] max steps of a wave
 };
 
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(BLOCK) void tracepk_kernel(TracePkArgs a) {
   for (uint32_t packet = blockIdx.x * (BLOCK / 64) + (uint32_t)wave; packet < n_packets; packet += wave_stride) {
   const uint32_t slot = packet * 64u + (uint32_t)lane;
   const float4 rd4 = a.rq.d[slot];
-  const float4 ro4 = a.rq.o[slot];
+  const float4 ro4 = make_float4(a.origin[0], a.origin[1], a.origin[2], 0.0f);
   const bool valid = rd4.w != 0.0f;
   const f3 S = mk(ro4.x, ro4.y, ro4.z), d = mk(rd4.x, rd4.y, rd4.z);
   const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);

@@ -23,7 +23,7 @@ namespace ezd {
 constexpr uint32_t TRACE_POOL_MIN = 8; // smallest reservation: short queues are spread over every wave
 
 struct RayQueue {
-  float4* o; // origin.xyz, -
+  float4* o; // origin.xyz, -   (not stored for primary rays: TraceQArgs.origin)
   float4* d; // dir.xyz, valid (1) / skip (0)
 };
 
@@ -33,6 +33,8 @@ struct TraceQArgs {
   int2* hits;
   const uint32_t* n_paths; // device count; rays = n_paths * rays_per_path
   uint32_t rays_per_path;
+  uint32_t const_origin;   // 1: every ray of this queue starts at `origin` (primary rays); rq.o is not read
+  float origin[3];
   uint32_t* head;          // queue head (device, zeroed per launch)
   unsigned long long* counters;
   int32_t leaf_threshold;  // lanes waiting at a leaf that trigger the triangle phase
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
             if (a.redo_flag) a.redo_flag[rs] = 0u;
           }
           nx_slot = rs;
-          nx_o = a.rq.o[rs];
+          nx_o = a.const_origin ? make_float4(a.origin[0], a.origin[1], a.origin[2], 0.0f) : a.rq.o[rs];
           nx_d = a.rq.d[rs];
           nx_valid = true;
         }

@@ -52,6 +52,8 @@ struct WfArgs {
   const uint32_t* n_in;    // paths in the input queue (device)
   uint32_t* n_out;         // paths in the output queue (device, atomically grown)
   int32_t bounce;          // the bounce this stage starts (0 = consumes the primary hits)
+  const float* sobol_tab;  // [frame - frame_first][8]: sobol(d, grayCode(frame + 1)), filled once per chunk
+  uint32_t scatter;        // queue order of the primary rays: see queue_to_sample (1 = identity)
 };
 
 EZD void slot_to_pixel(const int2* blocks, int n_blocks, uint32_t slot, uint32_t frame_first, int& x, int& y,
@@ -66,6 +68,20 @@ EZD void slot_to_pixel(const int2* blocks, int n_blocks, uint32_t slot, uint32_t
   frame = frame_first + fk;
 }
 
+// Queue order of the primary rays.  Sample slots are laid out [frame][16x16 block][8x8 sub-block]
+// [lane]; taking queue position = sample slot would hand a wave pools of 256 rays from ONE 16x16
+// pixel block -- all cheap (sky) or all expensive (the Bunny), and the launch ends with the waves
+// that drew the expensive ones.  So the 8x8 sub-blocks of a frame are visited in a scattered
+// order, sub-block (r * scatter) mod n_sub at position r (scatter coprime to n_sub): a pool is four
+// sub-blocks from distant parts of the image and every pool costs about the same.
+EZD uint32_t queue_to_sample(uint32_t qslot, uint32_t n_blocks, uint32_t scatter) {
+  const uint32_t n_sub = n_blocks * 4u;
+  const uint32_t q = qslot >> 6;
+  const uint32_t fk = q / n_sub, r = q - fk * n_sub;
+  const uint32_t r2 = (uint32_t)(((unsigned long long)r * scatter) % n_sub);
+  return ((fk * n_sub + r2) << 6) | (qslot & 63u);
+}
+
 // ---------------------------------------------------------------------------
 // raygen: P5/fsh:315-318, 920-925
 __global__ __launch_bounds__(BLOCK) void raygen_kernel(WfArgs a) {
@@ -74,7 +90,7 @@ __global__ __launch_bounds__(BLOCK) void raygen_kernel(WfArgs a) {
   if (slot == 0) *a.n_out = a.n_slots; // stage 0's path count, read by the first trace launch
   int x, y;
   uint32_t frame;
-  slot_to_pixel(a.blocks, a.n_blocks, slot, a.frame_first, x, y, frame);
+  slot_to_pixel(a.blocks, a.n_blocks, queue_to_sample(slot, (uint32_t)a.n_blocks, a.scatter), a.frame_first, x, y, frame);
   const EzrtRenderParams& p = a.p;
   if (!pixel_owned(p, x, y)) {
     a.rq_out.d[slot] = make_float4(0, 0, 0, 0.0f);
@@ -91,9 +107,10 @@ __global__ __launch_bounds__(BLOCK) void raygen_kernel(WfArgs a) {
   const float* m = p.camera_rotate;
   f3 dir = mk(m[0] * vx + m[4] * vy + m[8] * vz, m[1] * vx + m[5] * vy + m[9] * vz, m[2] * vx + m[6] * vy + m[10] * vz);
   dir = normalize(dir);
-  a.rq_out.o[slot] = make_float4(p.eye[0], p.eye[1], p.eye[2], 0.0f);
+  // only the direction is stored: every primary ray starts at the eye (the trace takes it from its
+  // arguments) and the shading stage re-derives the RNG state from the slot (two hashes) -- 32 B per
+  // pixel-sample less to write here and 48 B less to read downstream
   a.rq_out.d[slot] = make_float4(dir.x, dir.y, dir.z, 1.0f);
-  a.st_out.s3[slot] = make_float4(0, 0, 0, __uint_as_float(seed));
 }
 
 // ---------------------------------------------------------------------------
@@ -162,12 +179,13 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(WfArgs a) {
     const uint32_t ii = live ? i : 0u;
     const uint32_t rslot = (b == 0 || !MIS) ? ii : (2u * ii + 1u);
     const float4 rd4 = a.rq_in.d[rslot];
-    const float4 ro4 = a.rq_in.o[rslot];
     const int2 h = a.hits[rslot];
-    const float4 s3 = a.st_in.s3[ii];
-    float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, s4 = s0;
+    float4 ro4 = make_float4(p.eye[0], p.eye[1], p.eye[2], 0.0f);
+    float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, s3 = s0, s4 = s0;
     int2 sh = make_int2(-1, 0);
     if (b > 0) {
+      ro4 = a.rq_in.o[rslot];
+      s3 = a.st_in.s3[ii];
       s0 = a.st_in.s0[ii];
       s1 = a.st_in.s1[ii];
       s2 = a.st_in.s2[ii];
@@ -181,7 +199,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(WfArgs a) {
       f3 colour = mk(0, 0, 0);
       const f3 rd = mk(rd4.x, rd4.y, rd4.z);
       if (b == 0) {
-        sslot = i;
+        sslot = queue_to_sample(i, (uint32_t)a.n_blocks, a.scatter);
         if (rd4.w == 0.0f) {
           live = false; // pixel not owned by this shard
         } else {
@@ -192,7 +210,14 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(WfArgs a) {
           } else {
             shade_point<P5TRI>(sc, h.x, __int_as_float(h.y), mk(ro4.x, ro4.y, ro4.z), rd, hit);
             Le0 = hit.m.emissive;
-            seed = __float_as_uint(s3.w);
+            { // RNG state after the two anti-aliasing draws of ray generation (P5/fsh:315-318, 920-921)
+              int x0, y0;
+              uint32_t f0;
+              slot_to_pixel(a.blocks, a.n_blocks, sslot, a.frame_first, x0, y0, f0);
+              seed = ((uint32_t)x0 * 1973u + (uint32_t)y0 * 9277u + f0 * 26699u) | 1u;
+              wang_hash(seed);
+              wang_hash(seed);
+            }
           }
         }
       } else {
@@ -274,10 +299,10 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(WfArgs a) {
         if (INTEG >= 50) {
           float cpu, cpv;
           cp_offsets((uint32_t)x, (uint32_t)y, cpu, cpv);
-          const uint32_t gray = gray_code(frame + 1u);
-          uint32_t d0 = ((uint32_t)b * 2u) & 7u, d1 = ((uint32_t)b * 2u + 1u) & 7u;
-          xi1 = cp_rotate(sobol(d0, gray), cpu);
-          xi2 = cp_rotate(sobol(d1, gray), cpv);
+          const float* sob = a.sobol_tab + (size_t)(frame - a.frame_first) * 8u; // sobol(d, grayCode(frame + 1))
+          const uint32_t d0 = ((uint32_t)b * 2u) & 7u, d1 = ((uint32_t)b * 2u + 1u) & 7u;
+          xi1 = cp_rotate(sob[d0], cpu);
+          xi2 = cp_rotate(sob[d1], cpv);
         } else {
           xi1 = rnd(seed);
           xi2 = rnd(seed);
