@@ -78,6 +78,10 @@ struct Counters { // per-thread, registers
 
 // ---------------------------------------------------------------------------
 // RNG: P5/fsh:315-331
+// Lane mask of a predicate.  (HIP's __ballot takes an int: the bool is first materialised as 0/1
+// in a VGPR and compared again -- two VALU slots per test in a VALU-bound loop.)
+EZD unsigned long long ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
 EZD uint32_t wang_hash(uint32_t& seed) {
   seed = (seed ^ 61u) ^ (seed >> 16);
   seed *= 9u;

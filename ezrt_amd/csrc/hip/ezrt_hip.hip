@@ -370,7 +370,8 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
   const size_t lds_t = lds_fixed + (size_t)lds_nodes * 80;
   const unsigned trace_grid_full = (unsigned)(s->num_cus * blocks_per_cu);
   unsigned shade_grid = (unsigned)((n_slots + SHADE_BLOCK - 1) / SHADE_BLOCK);
-  if (shade_grid > 2048u) shade_grid = 2048u;
+  const unsigned shade_grid_max = 2048u * 1024u / SHADE_BLOCK; // 8 workgroup-iterations' worth of resident threads
+  if (shade_grid > shade_grid_max) shade_grid = shade_grid_max;
 
   for (int b = 0; b <= p->max_bounce; b++) {
     const int in = b & 1, out = in ^ 1;

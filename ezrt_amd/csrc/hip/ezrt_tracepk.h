@@ -50,13 +50,13 @@ __global__ __launch_bounds__(BLOCK) void tracepk_kernel(TracePkArgs a) {
   const bool valid = rd4.w != 0.0f;
   const f3 S = mk(ro4.x, ro4.y, ro4.z), d = mk(rd4.x, rd4.y, rd4.z);
   const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  const bool any_wild = __ballot(valid && !ray_is_tame(S, inv)) != 0ull;
+  const bool any_wild = ballot(valid && !ray_is_tame(S, inv)) != 0ull;
   float best_t = INF;
   int32_t best_tri = -1;
   bool ambiguous = false;
   uint32_t dbg_inner = 0, dbg_tri = 0;
 
-  unsigned long long cur_mask = __ballot(valid);
+  unsigned long long cur_mask = ballot(valid);
   uint32_t cur_ref = a.root_ref;
   int sp = 0;
   const unsigned long long lane_bit = 1ull << lane;
@@ -108,11 +108,11 @@ __global__ __launch_bounds__(BLOCK) void tracepk_kernel(TracePkArgs a) {
           h2 = d2 > 0.0f;
           lf = d1 < d2;
         }
-        const unsigned long long m1 = __ballot(h1), m2 = __ballot(h2);
+        const unsigned long long m1 = ballot(h1), m2 = ballot(h2);
         const uint32_t left = __float_as_uint(q3.x), right = __float_as_uint(q3.y);
         if (m1 && m2) {
           // both children wanted by someone: majority vote on which goes first (speed only)
-          const int nl = (int)__popcll(__ballot(h1 && h2 && lf)), nr = (int)__popcll(__ballot(h1 && h2 && !lf));
+          const int nl = (int)__popcll(ballot(h1 && h2 && lf)), nr = (int)__popcll(ballot(h1 && h2 && !lf));
           const bool left_first = nl >= nr;
           const uint32_t far_ref = left_first ? right : left;
           const unsigned long long far_mask = left_first ? m2 : m1;
@@ -149,14 +149,14 @@ __global__ __launch_bounds__(BLOCK) void tracepk_kernel(TracePkArgs a) {
   }
   const bool redo = valid && (bailout || ambiguous);
   if (valid && !redo) a.hits[slot] = make_int2(best_tri, __float_as_int(best_t));
-  const unsigned long long rm = __ballot(redo);
+  const unsigned long long rm = ballot(redo);
   if (rm) { // one atomic per wave; slots of a wave stay contiguous in the redo list
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(a.redo_count, (uint32_t)__popcll(rm));
     base = __shfl(base, 0, 64);
     if (redo) a.redo_slots[base + lane_rank(rm)] = slot;
   }
-  ndone_total += (unsigned long long)__popcll(__ballot(valid && !redo));
+  ndone_total += (unsigned long long)__popcll(ballot(valid && !redo));
   } // packets
   if (lane == 0 && ndone_total) atomicAdd(&a.counters[EZRT_CTR_RAYS], ndone_total); // redone rays are counted by traceq
 }

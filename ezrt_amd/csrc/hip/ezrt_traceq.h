@@ -139,7 +139,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
     wave_iters++;
     // ---- refill: lanes without work adopt their prefetched ray, then prefetch another
     const bool want = !work;
-    if (__ballot(want)) {
+    if (ballot(want)) {
       if (want && nx_valid) {
         nx_valid = false;
         if (nx_d.w != 0.0f) {
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
         }
       }
       const bool need = !nx_valid && !exhausted;
-      const unsigned long long m = __ballot(need);
+      const unsigned long long m = ballot(need);
       if (m) {
         const uint32_t cnt = (uint32_t)__popcll(m);
         const uint32_t r = lane_rank(m);
@@ -203,15 +203,15 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
         }
       }
     }
-    if (!__ballot(work || nx_valid)) break;
+    if (!ballot(work || nx_valid)) break;
 
     // ---- work stealing: lanes with nothing left to fetch take the oldest pending subtree of a busy lane
     if (a.steal) {
       const bool idle = !work && !nx_valid;
-      const unsigned long long im = __ballot(idle);
+      const unsigned long long im = ballot(idle);
       if (im) {
         const bool rich = work && (sp - sb) >= 1;
-        const unsigned long long vm = __ballot(rich);
+        const unsigned long long vm = ballot(rich);
         if (vm) {
           const int ni = (int)__popcll(im), nv = (int)__popcll(vm);
           const int n = ni < nv ? ni : nv;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
         q3 = r[3];
       }
       float d1, d2;
-      if (__ballot(wild)) { // some lane's ray has a zero/NaN direction component: exact select form
+      if (ballot(wild)) { // some lane's ray has a zero/NaN direction component: exact select form
         d1 = hit_aabb(S, inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));
         d2 = hit_aabb(S, inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w));
       } else {
@@ -312,10 +312,10 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
     // nobody can step.  (Issuing the node and triangle fetches of one iteration together was tried:
     // +22 VGPRs cost a wave per SIMD and 10 % -- see DESIGN.md.)
     const bool at_leaf = work && (ref & LEAF_BIT);
-    const unsigned long long lm = __ballot(at_leaf);
+    const unsigned long long lm = ballot(at_leaf);
     if (lm) {
       const int Lc = (int)__popcll(lm);
-      const bool go = Lc >= a.leaf_threshold || !__ballot(work && !(ref & LEAF_BIT));
+      const bool go = Lc >= a.leaf_threshold || !ballot(work && !(ref & LEAF_BIT));
       if (go) {
         if (!FULLCTR && Lc <= 32) {
           // cooperative: g = 64 / Lc lanes (power of two) per waiting ray

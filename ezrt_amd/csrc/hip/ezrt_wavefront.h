@@ -115,13 +115,14 @@ __global__ __launch_bounds__(BLOCK) void raygen_kernel(WfArgs a) {
 
 // ---------------------------------------------------------------------------
 // shading stage
-constexpr int SHADE_BLOCK = 1024; // 16 waves share ONE queue-tail atomic per iteration (see block_alloc)
+constexpr int SHADE_BLOCK = 512; // 8 waves share ONE queue-tail atomic per iteration (see block_alloc); two workgroups
+                                 // per CU, so one computes while the other sits in its barriers (1024: -3 %, 256: atomic-bound)
 
 // Compaction slot for every lane with `want`: wave ballots -> per-wave counts in LDS -> one
 // atomicAdd per 1024-thread workgroup -> wave offsets.  A single queue-tail word only sustains
 // ~88 atomics/us, so per-wave atomics (118 k per stage on C2) would cost more than the shading.
 EZD uint32_t block_alloc(uint32_t* counter, bool want, uint32_t* lds /* [SHADE_BLOCK/64 + 1] */) {
-  const unsigned long long m = __ballot(want);
+  const unsigned long long m = ballot(want);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr int NW = SHADE_BLOCK / 64;
   __syncthreads(); // previous iteration's readers are done with lds
@@ -141,7 +142,7 @@ EZD uint32_t block_alloc(uint32_t* counter, bool want, uint32_t* lds /* [SHADE_B
 }
 
 EZD uint32_t wave_alloc(uint32_t* counter, bool want) {
-  unsigned long long m = __ballot(want);
+  unsigned long long m = ballot(want);
   if (!m) return 0;
   uint32_t base = 0;
   const int leader = __ffsll((long long)m) - 1;
@@ -150,215 +151,288 @@ EZD uint32_t wave_alloc(uint32_t* counter, bool want) {
   return base + lane_rank(m);
 }
 
-template <int INTEG, bool FULLCTR>
-__global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(WfArgs a) {
-  __shared__ uint32_t alloc_lds[SHADE_BLOCK / 64 + 1];
+// Block-wide exclusive rank of the lanes with `want` (no global atomic); total = their number.
+EZD uint32_t block_rank(bool want, uint32_t* lds /* [SHADE_BLOCK/64 + 1] */, uint32_t& total) {
+  const unsigned long long m = ballot(want);
+  const int wave = threadIdx.x >> 6;
+  constexpr int NW = SHADE_BLOCK / 64;
+  __syncthreads(); // previous readers are done with lds
+  if ((threadIdx.x & 63) == 0) lds[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < NW; w++) {
+      uint32_t c = lds[w];
+      lds[w] = t;
+      t += c;
+    }
+    lds[NW] = t;
+  }
+  __syncthreads();
+  total = lds[NW];
+  return lds[wave] + lane_rank(m);
+}
+
+// What one path hands to the compaction at the end of a shading stage.
+struct ShadeOut {
+  bool emit;
+  uint32_t sslot, seed, flags;
+  f3 history, Lo, Le0, f_r, shadowC, rayL, shadowL, P;
+  float cosine, pdf;
+};
+
+// One path through stage b.  PASS 0: everything inline (b == 0: primary hits are coherent).
+// PASS 1 (b > 0): everything but the surface interaction -- a path whose ray hit a triangle and that
+// is still alive returns true ("deferred") and touches nothing.  PASS 2: the deferred paths, regrouped
+// densely by the caller.  Bounce rays mostly leave the scene (90 % on C2), so without the regrouping
+// every wave ran the ~700-instruction surface code for a handful of its lanes.
+template <int INTEG, bool FULLCTR, int PASS>
+EZD bool shade_path(const WfArgs& a, const uint32_t i, bool live, Counters& ctr, uint32_t& n_samples, ShadeOut& o) {
   constexpr bool P5TRI = (INTEG >= 50);
   constexpr bool MIS = (INTEG == EZRT_INTEGRATOR_P5_MIS);
   const DevScene& sc = a.sc;
   const EzrtRenderParams& p = a.p;
   const int b = a.bounce;
+  uint32_t sslot = 0, seed = 0, flags = 0;
+  f3 history = mk(1, 1, 1), Lo = mk(0, 0, 0), Le0 = mk(0, 0, 0), f_r = mk(0, 0, 0), shadowC = mk(0, 0, 0);
+  float cosine = 0.0f, pdf = 1.0f;
+  f3 rayL = mk(0, 0, 0), shadowL = mk(0, 0, 0);
+  Hit hit;
+  hit.P = mk(0, 0, 0);
+  o.emit = false;
+
+  // first-level loads: addresses depend on i only, so issue them all up front (one memory
+  // round trip) instead of discovering them one branch at a time
+  const uint32_t ii = live ? i : 0u;
+  const uint32_t rslot = (b == 0 || !MIS) ? ii : (2u * ii + 1u);
+  const float4 rd4 = a.rq_in.d[rslot];
+  const int2 h = a.hits[rslot];
+  float4 ro4 = make_float4(p.eye[0], p.eye[1], p.eye[2], 0.0f);
+  float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, s3 = s0, s4 = s0;
+  int2 sh = make_int2(-1, 0);
+  if (PASS != 0) {
+    ro4 = a.rq_in.o[rslot];
+    s3 = a.st_in.s3[ii];
+    s0 = a.st_in.s0[ii];
+    s1 = a.st_in.s1[ii];
+    s2 = a.st_in.s2[ii];
+    if (MIS) {
+      s4 = a.st_in.s4[ii];
+      sh = a.hits[2u * ii];
+    }
+  }
+  bool done = false;
+  if (!live) return false;
+  f3 colour = mk(0, 0, 0);
+  const f3 rd = mk(rd4.x, rd4.y, rd4.z);
+  if (PASS == 0) {
+    sslot = queue_to_sample(i, (uint32_t)a.n_blocks, a.scatter);
+    if (rd4.w == 0.0f) {
+      live = false; // pixel not owned by this shard
+    } else {
+      n_samples = n_samples + 1;
+      if (h.x < 0) { // primary miss: P5/fsh:931-933
+        colour = hdr_color<FULLCTR>(sc, rd, p.env_clamp, ctr);
+        done = true;
+      } else {
+        shade_point<P5TRI>(sc, h.x, __int_as_float(h.y), mk(ro4.x, ro4.y, ro4.z), rd, hit);
+        Le0 = hit.m.emissive;
+        { // RNG state after the two anti-aliasing draws of ray generation (P5/fsh:315-318, 920-921)
+          int x0, y0;
+          uint32_t f0;
+          slot_to_pixel(a.blocks, a.n_blocks, sslot, a.frame_first, x0, y0, f0);
+          seed = ((uint32_t)x0 * 1973u + (uint32_t)y0 * 9277u + f0 * 26699u) | 1u;
+          wang_hash(seed);
+          wang_hash(seed);
+        }
+      }
+    }
+  } else {
+    history = mk(s0.x, s0.y, s0.z);
+    cosine = s0.w;
+    Lo = mk(s1.x, s1.y, s1.z);
+    pdf = s1.w;
+    f_r = mk(s2.x, s2.y, s2.z);
+    sslot = __float_as_uint(s2.w);
+    Le0 = mk(s3.x, s3.y, s3.z);
+    seed = __float_as_uint(s3.w);
+    if (MIS) {
+      flags = __float_as_uint(s4.w);
+      if (flags & FLAG_SHADOW_SHOT) { // P5/fsh:826-841
+        if (sh.x < 0) {
+          Lo = Lo + mk(s4.x, s4.y, s4.z);
+          if (FULLCTR && PASS != 2) {
+            ctr.envmap++;
+            ctr.envcache++;
+          }
+        }
+      }
+    }
+    if (MIS && (flags & FLAG_TERMINATE)) {
+      done = true;
+    } else if (MIS && (flags & FLAG_PDF_DEAD)) {
+      done = true;
+    } else {
+      if (h.x < 0) {
+        f3 sky = hdr_color<FULLCTR>(sc, rd, p.env_clamp, ctr);
+        if (MIS) {
+          float pdf_light = hdr_pdf<FULLCTR>(sc, rd, ctr);
+          float w = mis_mix_weight(pdf, pdf_light);
+          Lo = Lo + (((history * w) * sky) * f_r) * cosine / pdf;
+        } else {
+          Lo = Lo + ((history * sky) * f_r) * cosine / pdf;
+        }
+        done = true;
+      } else {
+        if (PASS == 1) return true; // surface interaction: regrouped into dense waves by the caller
+        shade_point<P5TRI>(sc, h.x, __int_as_float(h.y), mk(ro4.x, ro4.y, ro4.z), rd, hit);
+        Lo = Lo + ((history * hit.m.emissive) * f_r) * cosine / pdf;
+        history = history * (f_r * cosine / pdf);
+      }
+    }
+    if (done) colour = Le0 + Lo;
+  }
+  if (live && !done && b >= p.max_bounce) {
+    colour = Le0 + Lo;
+    done = true;
+  }
+  if (live && done) a.samples[sslot] = make_float4(colour.x, colour.y, colour.z, 1.0f);
+
+  if (live && !done) {
+    // ---- start bounce b (loop body of pathTracing*, P5/fsh:767-804 / 815-887)
+    int x, y;
+    uint32_t frame;
+    slot_to_pixel(a.blocks, a.n_blocks, sslot, a.frame_first, x, y, frame);
+    const f3 V = -hit.viewDir, N = hit.N;
+    flags = 0;
+    bool shoot = true;
+    if (MIS) {
+      float h1 = rnd(seed);
+      float h2 = rnd(seed);
+      f3 Lh = sample_hdr<FULLCTR>(sc, h1, h2, ctr);
+      if (dot(N, Lh) > 0.0f) {
+        flags |= FLAG_SHADOW_SHOT;
+        shadowL = Lh;
+        // contribution if unoccluded, evaluated eagerly (pure functions of the path state)
+        Counters dummy = {0, 0, 0, 0, 0, 0, 0};
+        f3 color = hdr_color<false>(sc, Lh, p.env_clamp, dummy);
+        float pdf_light = hdr_pdf<false>(sc, Lh, dummy);
+        f3 fr = brdf_evaluate<false>(V, N, Lh, mk(0, 0, 0), mk(0, 0, 0), hit.m);
+        float pdf_brdf = brdf_pdf(V, N, Lh, hit.m);
+        float w = mis_mix_weight(pdf_light, pdf_brdf);
+        shadowC = (((history * w) * color) * fr) * dot(N, Lh) / pdf_light;
+      }
+    }
+    float xi1, xi2;
+    if (INTEG >= 50) {
+      float cpu, cpv;
+      cp_offsets((uint32_t)x, (uint32_t)y, cpu, cpv);
+      const float* sob = a.sobol_tab + (size_t)(frame - a.frame_first) * 8u; // sobol(d, grayCode(frame + 1))
+      const uint32_t d0 = ((uint32_t)b * 2u) & 7u, d1 = ((uint32_t)b * 2u + 1u) & 7u;
+      xi1 = cp_rotate(sob[d0], cpu);
+      xi2 = cp_rotate(sob[d1], cpv);
+    } else {
+      xi1 = rnd(seed);
+      xi2 = rnd(seed);
+    }
+    if (MIS) {
+      float xi3 = rnd(seed);
+      rayL = sample_brdf(xi1, xi2, xi3, V, N, hit.m);
+      cosine = dot(N, rayL);
+      if (cosine <= 0.0f) {
+        shoot = false;
+        flags |= FLAG_TERMINATE;
+      } else {
+        f_r = brdf_evaluate<false>(V, N, rayL, mk(0, 0, 0), mk(0, 0, 0), hit.m);
+        pdf = brdf_pdf(V, N, rayL, hit.m);
+        if (pdf <= 0.0f) flags |= FLAG_PDF_DEAD;
+      }
+    } else {
+      rayL = to_normal_hemisphere(sample_hemisphere(xi1, xi2), N);
+      pdf = 1.0f / (2.0f * PI);
+      cosine = ez_max(0.0f, dot(rayL, N));
+      if (INTEG == EZRT_INTEGRATOR_P3_DIFFUSE) {
+        f_r = hit.m.baseColor / PI;
+      } else {
+        f3 tangent, bitangent;
+        get_tangent(N, tangent, bitangent);
+        f_r = brdf_evaluate<INTEG == EZRT_INTEGRATOR_P4_DISNEY>(V, N, rayL, tangent, bitangent, hit.m);
+      }
+    }
+    if (!shoot && !(flags & FLAG_SHADOW_SHOT)) { // nothing pending: the path ends here
+      f3 c2 = Le0 + Lo;
+      a.samples[sslot] = make_float4(c2.x, c2.y, c2.z, 1.0f);
+    } else {
+      o.emit = true;
+      if (!shoot) rayL = mk(0, 0, 0);
+    }
+  }
+  o.sslot = sslot;
+  o.seed = seed;
+  o.flags = flags;
+  o.history = history;
+  o.Lo = Lo;
+  o.Le0 = Le0;
+  o.f_r = f_r;
+  o.shadowC = shadowC;
+  o.rayL = rayL;
+  o.shadowL = shadowL;
+  o.P = hit.P;
+  o.cosine = cosine;
+  o.pdf = pdf;
+  return false;
+}
+
+// compaction of the surviving paths into the next queue: one ballot per wave, one atomic per workgroup
+template <bool MIS>
+EZD void shade_emit(const WfArgs& a, const ShadeOut& o, uint32_t* alloc_lds) {
+  const uint32_t k = block_alloc(a.n_out, o.emit, alloc_lds);
+  if (!o.emit) return;
+  a.st_out.s0[k] = make_float4(o.history.x, o.history.y, o.history.z, o.cosine);
+  a.st_out.s1[k] = make_float4(o.Lo.x, o.Lo.y, o.Lo.z, o.pdf);
+  a.st_out.s2[k] = make_float4(o.f_r.x, o.f_r.y, o.f_r.z, __uint_as_float(o.sslot));
+  a.st_out.s3[k] = make_float4(o.Le0.x, o.Le0.y, o.Le0.z, __uint_as_float(o.seed));
+  const bool shoot = !(o.flags & FLAG_TERMINATE);
+  if (MIS) {
+    a.st_out.s4[k] = make_float4(o.shadowC.x, o.shadowC.y, o.shadowC.z, __uint_as_float(o.flags));
+    a.rq_out.o[2u * k] = make_float4(o.P.x, o.P.y, o.P.z, 0.0f);
+    a.rq_out.d[2u * k] = make_float4(o.shadowL.x, o.shadowL.y, o.shadowL.z, (o.flags & FLAG_SHADOW_SHOT) ? 1.0f : 0.0f);
+    a.rq_out.o[2u * k + 1u] = make_float4(o.P.x, o.P.y, o.P.z, 0.0f);
+    a.rq_out.d[2u * k + 1u] = make_float4(o.rayL.x, o.rayL.y, o.rayL.z, shoot ? 1.0f : 0.0f);
+  } else {
+    a.rq_out.o[k] = make_float4(o.P.x, o.P.y, o.P.z, 0.0f);
+    a.rq_out.d[k] = make_float4(o.rayL.x, o.rayL.y, o.rayL.z, 1.0f);
+  }
+}
+
+template <int INTEG, bool FULLCTR>
+__global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_kernel(WfArgs a) {
+  __shared__ uint32_t alloc_lds[SHADE_BLOCK / 64 + 1];
+  __shared__ uint32_t defer_list[SHADE_BLOCK];
+  constexpr bool MIS = (INTEG == EZRT_INTEGRATOR_P5_MIS);
+  const int b = a.bounce;
   const uint32_t n_in = (b == 0) ? a.n_slots : *a.n_in;
   const uint32_t stride = gridDim.x * SHADE_BLOCK;
-  const uint32_t n_round = (n_in + stride - 1) / stride * stride; // keep waves whole for the ballots
+  const uint32_t n_round = (n_in + stride - 1) / stride * stride; // keep workgroups whole for the barriers
   Counters ctr = {0, 0, 0, 0, 0, 0, 0};
   uint32_t n_samples = 0;
 
   for (uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x; i < n_round; i += stride) {
-    bool live = i < n_in;       // this lane holds a path
-    bool emit = false;          // ... that continues into the next queue
-    uint32_t sslot = 0, seed = 0, flags = 0;
-    f3 history = mk(1, 1, 1), Lo = mk(0, 0, 0), Le0 = mk(0, 0, 0), f_r = mk(0, 0, 0), shadowC = mk(0, 0, 0);
-    float cosine = 0.0f, pdf = 1.0f;
-    f3 rayL = mk(0, 0, 0), shadowL = mk(0, 0, 0);
-    Hit hit;
-    hit.P = mk(0, 0, 0);
-
-    // first-level loads: addresses depend on i only, so issue them all up front (one memory
-    // round trip) instead of discovering them one branch at a time
-    const uint32_t ii = live ? i : 0u;
-    const uint32_t rslot = (b == 0 || !MIS) ? ii : (2u * ii + 1u);
-    const float4 rd4 = a.rq_in.d[rslot];
-    const int2 h = a.hits[rslot];
-    float4 ro4 = make_float4(p.eye[0], p.eye[1], p.eye[2], 0.0f);
-    float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, s3 = s0, s4 = s0;
-    int2 sh = make_int2(-1, 0);
-    if (b > 0) {
-      ro4 = a.rq_in.o[rslot];
-      s3 = a.st_in.s3[ii];
-      s0 = a.st_in.s0[ii];
-      s1 = a.st_in.s1[ii];
-      s2 = a.st_in.s2[ii];
-      if (MIS) {
-        s4 = a.st_in.s4[ii];
-        sh = a.hits[2u * ii];
-      }
-    }
-    bool done = false;
-    if (live) {
-      f3 colour = mk(0, 0, 0);
-      const f3 rd = mk(rd4.x, rd4.y, rd4.z);
-      if (b == 0) {
-        sslot = queue_to_sample(i, (uint32_t)a.n_blocks, a.scatter);
-        if (rd4.w == 0.0f) {
-          live = false; // pixel not owned by this shard
-        } else {
-          n_samples = n_samples + 1;
-          if (h.x < 0) { // primary miss: P5/fsh:931-933
-            colour = hdr_color<FULLCTR>(sc, rd, p.env_clamp, ctr);
-            done = true;
-          } else {
-            shade_point<P5TRI>(sc, h.x, __int_as_float(h.y), mk(ro4.x, ro4.y, ro4.z), rd, hit);
-            Le0 = hit.m.emissive;
-            { // RNG state after the two anti-aliasing draws of ray generation (P5/fsh:315-318, 920-921)
-              int x0, y0;
-              uint32_t f0;
-              slot_to_pixel(a.blocks, a.n_blocks, sslot, a.frame_first, x0, y0, f0);
-              seed = ((uint32_t)x0 * 1973u + (uint32_t)y0 * 9277u + f0 * 26699u) | 1u;
-              wang_hash(seed);
-              wang_hash(seed);
-            }
-          }
-        }
-      } else {
-        history = mk(s0.x, s0.y, s0.z);
-        cosine = s0.w;
-        Lo = mk(s1.x, s1.y, s1.z);
-        pdf = s1.w;
-        f_r = mk(s2.x, s2.y, s2.z);
-        sslot = __float_as_uint(s2.w);
-        Le0 = mk(s3.x, s3.y, s3.z);
-        seed = __float_as_uint(s3.w);
-        if (MIS) {
-          flags = __float_as_uint(s4.w);
-          if (flags & FLAG_SHADOW_SHOT) { // P5/fsh:826-841
-            if (sh.x < 0) {
-              Lo = Lo + mk(s4.x, s4.y, s4.z);
-              if (FULLCTR) {
-                ctr.envmap++;
-                ctr.envcache++;
-              }
-            }
-          }
-        }
-        if (MIS && (flags & FLAG_TERMINATE)) {
-          done = true;
-        } else if (MIS && (flags & FLAG_PDF_DEAD)) {
-          done = true;
-        } else {
-          if (h.x < 0) {
-            f3 sky = hdr_color<FULLCTR>(sc, rd, p.env_clamp, ctr);
-            if (MIS) {
-              float pdf_light = hdr_pdf<FULLCTR>(sc, rd, ctr);
-              float w = mis_mix_weight(pdf, pdf_light);
-              Lo = Lo + (((history * w) * sky) * f_r) * cosine / pdf;
-            } else {
-              Lo = Lo + ((history * sky) * f_r) * cosine / pdf;
-            }
-            done = true;
-          } else {
-            shade_point<P5TRI>(sc, h.x, __int_as_float(h.y), mk(ro4.x, ro4.y, ro4.z), rd, hit);
-            Lo = Lo + ((history * hit.m.emissive) * f_r) * cosine / pdf;
-            history = history * (f_r * cosine / pdf);
-          }
-        }
-        if (done) colour = Le0 + Lo;
-      }
-      if (live && !done && b >= p.max_bounce) {
-        colour = Le0 + Lo;
-        done = true;
-      }
-      if (live && done) a.samples[sslot] = make_float4(colour.x, colour.y, colour.z, 1.0f);
-
-      if (live && !done) {
-        // ---- start bounce b (loop body of pathTracing*, P5/fsh:767-804 / 815-887)
-        int x, y;
-        uint32_t frame;
-        slot_to_pixel(a.blocks, a.n_blocks, sslot, a.frame_first, x, y, frame);
-        const f3 V = -hit.viewDir, N = hit.N;
-        flags = 0;
-        bool shoot = true;
-        if (MIS) {
-          float h1 = rnd(seed);
-          float h2 = rnd(seed);
-          f3 Lh = sample_hdr<FULLCTR>(sc, h1, h2, ctr);
-          if (dot(N, Lh) > 0.0f) {
-            flags |= FLAG_SHADOW_SHOT;
-            shadowL = Lh;
-            // contribution if unoccluded, evaluated eagerly (pure functions of the path state)
-            Counters dummy = {0, 0, 0, 0, 0, 0, 0};
-            f3 color = hdr_color<false>(sc, Lh, p.env_clamp, dummy);
-            float pdf_light = hdr_pdf<false>(sc, Lh, dummy);
-            f3 fr = brdf_evaluate<false>(V, N, Lh, mk(0, 0, 0), mk(0, 0, 0), hit.m);
-            float pdf_brdf = brdf_pdf(V, N, Lh, hit.m);
-            float w = mis_mix_weight(pdf_light, pdf_brdf);
-            shadowC = (((history * w) * color) * fr) * dot(N, Lh) / pdf_light;
-          }
-        }
-        float xi1, xi2;
-        if (INTEG >= 50) {
-          float cpu, cpv;
-          cp_offsets((uint32_t)x, (uint32_t)y, cpu, cpv);
-          const float* sob = a.sobol_tab + (size_t)(frame - a.frame_first) * 8u; // sobol(d, grayCode(frame + 1))
-          const uint32_t d0 = ((uint32_t)b * 2u) & 7u, d1 = ((uint32_t)b * 2u + 1u) & 7u;
-          xi1 = cp_rotate(sob[d0], cpu);
-          xi2 = cp_rotate(sob[d1], cpv);
-        } else {
-          xi1 = rnd(seed);
-          xi2 = rnd(seed);
-        }
-        if (MIS) {
-          float xi3 = rnd(seed);
-          rayL = sample_brdf(xi1, xi2, xi3, V, N, hit.m);
-          cosine = dot(N, rayL);
-          if (cosine <= 0.0f) {
-            shoot = false;
-            flags |= FLAG_TERMINATE;
-          } else {
-            f_r = brdf_evaluate<false>(V, N, rayL, mk(0, 0, 0), mk(0, 0, 0), hit.m);
-            pdf = brdf_pdf(V, N, rayL, hit.m);
-            if (pdf <= 0.0f) flags |= FLAG_PDF_DEAD;
-          }
-        } else {
-          rayL = to_normal_hemisphere(sample_hemisphere(xi1, xi2), N);
-          pdf = 1.0f / (2.0f * PI);
-          cosine = ez_max(0.0f, dot(rayL, N));
-          if (INTEG == EZRT_INTEGRATOR_P3_DIFFUSE) {
-            f_r = hit.m.baseColor / PI;
-          } else {
-            f3 tangent, bitangent;
-            get_tangent(N, tangent, bitangent);
-            f_r = brdf_evaluate<INTEG == EZRT_INTEGRATOR_P4_DISNEY>(V, N, rayL, tangent, bitangent, hit.m);
-          }
-        }
-        if (!shoot && !(flags & FLAG_SHADOW_SHOT)) { // nothing pending: the path ends here
-          f3 c2 = Le0 + Lo;
-          a.samples[sslot] = make_float4(c2.x, c2.y, c2.z, 1.0f);
-        } else {
-          emit = true;
-          if (!shoot) rayL = mk(0, 0, 0);
-        }
-      }
-    }
-
-    // ---- compaction: one ballot + one atomic per wave
-    const uint32_t o = block_alloc(a.n_out, emit, alloc_lds);
-    if (emit) {
-      a.st_out.s0[o] = make_float4(history.x, history.y, history.z, cosine);
-      a.st_out.s1[o] = make_float4(Lo.x, Lo.y, Lo.z, pdf);
-      a.st_out.s2[o] = make_float4(f_r.x, f_r.y, f_r.z, __uint_as_float(sslot));
-      a.st_out.s3[o] = make_float4(Le0.x, Le0.y, Le0.z, __uint_as_float(seed));
-      const bool shoot = !(flags & FLAG_TERMINATE);
-      if (MIS) {
-        a.st_out.s4[o] = make_float4(shadowC.x, shadowC.y, shadowC.z, __uint_as_float(flags));
-        a.rq_out.o[2u * o] = make_float4(hit.P.x, hit.P.y, hit.P.z, 0.0f);
-        a.rq_out.d[2u * o] = make_float4(shadowL.x, shadowL.y, shadowL.z, (flags & FLAG_SHADOW_SHOT) ? 1.0f : 0.0f);
-        a.rq_out.o[2u * o + 1u] = make_float4(hit.P.x, hit.P.y, hit.P.z, 0.0f);
-        a.rq_out.d[2u * o + 1u] = make_float4(rayL.x, rayL.y, rayL.z, shoot ? 1.0f : 0.0f);
-      } else {
-        a.rq_out.o[o] = make_float4(hit.P.x, hit.P.y, hit.P.z, 0.0f);
-        a.rq_out.d[o] = make_float4(rayL.x, rayL.y, rayL.z, 1.0f);
-      }
+    ShadeOut o;
+    if (b == 0) {
+      shade_path<INTEG, FULLCTR, 0>(a, i, i < n_in, ctr, n_samples, o);
+      shade_emit<MIS>(a, o, alloc_lds);
+    } else {
+      const bool deferred = shade_path<INTEG, FULLCTR, 1>(a, i, i < n_in, ctr, n_samples, o);
+      uint32_t n_def = 0;
+      const uint32_t k = block_rank(deferred, alloc_lds, n_def);
+      if (deferred) defer_list[k] = i;
+      __syncthreads();
+      const bool has = threadIdx.x < n_def; // (n_def <= SHADE_BLOCK: one dense round)
+      const uint32_t j = has ? defer_list[threadIdx.x] : 0u;
+      o.emit = false;
+      if (has) shade_path<INTEG, FULLCTR, 2>(a, j, true, ctr, n_samples, o);
+      shade_emit<MIS>(a, o, alloc_lds);
     }
   }
 
