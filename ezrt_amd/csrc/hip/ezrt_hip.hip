@@ -68,6 +68,10 @@ struct Tuning {
   int trace_wps = 5;       // traceq_kernel register budget: waves per SIMD (4, 5, 6 or 8)
   int lds_nodes = 1 << 20; // cap on top-of-tree records staged in LDS
   int scatter = 1;         // primary rays enter the queue in a scattered 8x8 sub-block order (balances pools)
+  int pipes = 1;           // 2: sub-chunks of a call alternate between two scratch sets on two streams (measured:
+                           // the kernels do overlap, but each slows the other down and every stage's latency-bound
+                           // end is paid twice: 3.81 vs 3.65 ms per C2 frame)
+  int sub_frames = 0;      // frames per sub-chunk when pipelined (0: half the call's frames)
   int steal = 1;           // intra-wave work stealing in traceq_kernel (+ a redo launch for exact ties)
   int debug_stages = 0;    // print per-stage queue sizes (synchronises)
 };
@@ -79,7 +83,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel}, {"packet", &T
                               {"packet_budget", &Tuning::packet_budget}, {"leaf_threshold", &Tuning::leaf_threshold},
                               {"pool_div", &Tuning::pool_div}, {"pool_max", &Tuning::pool_max},
                               {"trace_wps", &Tuning::trace_wps}, {"lds_nodes", &Tuning::lds_nodes},
-                              {"steal", &Tuning::steal}, {"scatter", &Tuning::scatter}, {"debug_stages", &Tuning::debug_stages}};
+                              {"steal", &Tuning::steal}, {"pipes", &Tuning::pipes}, {"sub_frames", &Tuning::sub_frames}, {"scatter", &Tuning::scatter}, {"debug_stages", &Tuning::debug_stages}};
 Tuning tuning_from_env() {
   Tuning t;
   for (const TuningName& k : kTuning) {
@@ -91,6 +95,24 @@ Tuning tuning_from_env() {
 }
 
 } // namespace
+
+// Scratch of one sub-chunk of frames in flight (see EzrtScene::pipe).
+struct Pipe {
+  DevBuf<float4> samples;
+  // wavefront queues (ping-pong)
+  DevBuf<float4> rq_o[2], rq_d[2];
+  DevBuf<float4> st[2][5];
+  DevBuf<int2> hits2[2];        // hit records, ping-pong with the ray queues
+  DevBuf<uint32_t> redo_flag;   // per ray slot: already on the redo list
+  DevBuf<unsigned long long> wave_log; // debug_stages=2 only
+  DevBuf<float> sobol_tab;  // [frames of the chunk][8]
+  DevBuf<uint32_t> qcounts; // [0..63] path counts per stage, [64..99] trace queue heads, [100..115] debug,
+                            // [120] redo count, [121] redo queue head
+  DevBuf<uint32_t> redo_slots;
+  hipStream_t stream = nullptr;  // own stream (pipelined calls only)
+  hipEvent_t ev_done = nullptr;  // samples of the sub-chunk are complete
+  hipEvent_t ev_free = nullptr;  // ... and have been folded into the frame buffer
+};
 
 struct EzrtScene {
   int n_tri = 0, n_nodes = 0;
@@ -110,18 +132,11 @@ struct EzrtScene {
   std::vector<int2> blocks_host;
   EzrtRenderParams blocks_for; // params the block list was built for
   bool blocks_valid = false;
-  DevBuf<float4> samples;
   DevBuf<float4> accum_tmp;
-  // wavefront queues (ping-pong)
-  DevBuf<float4> rq_o[2], rq_d[2];
-  DevBuf<float4> st[2][5];
-  DevBuf<int2> hits2[2];        // hit records, ping-pong with the ray queues
-  DevBuf<uint32_t> redo_flag;   // per ray slot: already on the redo list
-  DevBuf<unsigned long long> wave_log; // debug_stages=2 only
-  DevBuf<float> sobol_tab;  // [frames of the chunk][8]
-  DevBuf<uint32_t> qcounts; // [0..63] path counts per stage, [64..99] trace queue heads, [100..115] debug,
-                            // [120] redo count, [121] redo queue head
-  DevBuf<uint32_t> redo_slots;
+  // Two independent sets of render scratch: a call's frames are cut into sub-chunks that alternate
+  // between them, each on its own stream, so one sub-chunk's latency-bound phases (the ends of the
+  // persistent trace launches, the late bounces, launch gaps) run under the other's bulk work.
+  Pipe pipe[2];
   int num_cus = 0;
   int n_inner = 0;
   Tuning tune = tuning_from_env();
@@ -242,6 +257,11 @@ int ensure_events(EzrtScene* s) {
     HIP_TRY(hipEventCreate(&s->ev_trace[i][0]));
     HIP_TRY(hipEventCreate(&s->ev_trace[i][1]));
   }
+  for (Pipe& q : s->pipe) {
+    HIP_TRY(hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&q.ev_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&q.ev_free, hipEventDisableTiming));
+  }
   return 0;
 }
 
@@ -266,28 +286,28 @@ void launch_shade(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
   }
 }
 
-int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t frame_first, uint32_t nf, hipStream_t st) {
+int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, uint32_t frame_first, uint32_t nf, hipStream_t st) {
   const bool mis = p->integrator == EZRT_INTEGRATOR_P5_MIS;
   const bool full = s->instr > 0;
   const size_t n_slots = (size_t)nb * BLOCK * nf;
   const size_t n_rays_max = n_slots * (mis ? 2 : 1);
   if (p->max_bounce > 32) return fail(EZRT_ERR_UNSUPPORTED, "max_bounce > 32: more stages than this build has queue counters for");
   for (int k = 0; k < 2; k++) {
-    HIP_TRY(s->rq_o[k].ensure(n_rays_max));
-    HIP_TRY(s->rq_d[k].ensure(n_rays_max));
-    for (int j = 0; j < (mis ? 5 : 4); j++) HIP_TRY(s->st[k][j].ensure(n_slots));
+    HIP_TRY(pp.rq_o[k].ensure(n_rays_max));
+    HIP_TRY(pp.rq_d[k].ensure(n_rays_max));
+    for (int j = 0; j < (mis ? 5 : 4); j++) HIP_TRY(pp.st[k][j].ensure(n_slots));
   }
-  HIP_TRY(s->hits2[0].ensure(n_rays_max));
-  HIP_TRY(s->hits2[1].ensure(n_rays_max));
-  HIP_TRY(s->redo_slots.ensure(n_rays_max));
-  if (s->redo_flag.n < n_rays_max) { // zeroed once; every entry set is cleared again by the redo launch
-    HIP_TRY(s->redo_flag.ensure(n_rays_max));
-    HIP_TRY(hipMemsetAsync(s->redo_flag.p, 0, n_rays_max * sizeof(uint32_t), st));
+  HIP_TRY(pp.hits2[0].ensure(n_rays_max));
+  HIP_TRY(pp.hits2[1].ensure(n_rays_max));
+  HIP_TRY(pp.redo_slots.ensure(n_rays_max));
+  if (pp.redo_flag.n < n_rays_max) { // zeroed once; every entry set is cleared again by the redo launch
+    HIP_TRY(pp.redo_flag.ensure(n_rays_max));
+    HIP_TRY(hipMemsetAsync(pp.redo_flag.p, 0, n_rays_max * sizeof(uint32_t), st));
   }
   // [0..63] paths per stage, [64..99] queue heads, [100..119] debug, [120,121] packet redo,
   // [128..] redo counts per stage, [192..] redo queue heads per stage
-  HIP_TRY(s->qcounts.ensure(256));
-  HIP_TRY(hipMemsetAsync(s->qcounts.p, 0, 256 * sizeof(uint32_t), st));
+  HIP_TRY(pp.qcounts.ensure(256));
+  HIP_TRY(hipMemsetAsync(pp.qcounts.p, 0, 256 * sizeof(uint32_t), st));
   if (!s->num_cus) {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -297,17 +317,17 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
   }
   auto queue = [&](int k) {
     RayQueue q;
-    q.o = s->rq_o[k].p;
-    q.d = s->rq_d[k].p;
+    q.o = pp.rq_o[k].p;
+    q.d = pp.rq_d[k].p;
     return q;
   };
   auto state = [&](int k) {
     PathState t;
-    t.s0 = s->st[k][0].p;
-    t.s1 = s->st[k][1].p;
-    t.s2 = s->st[k][2].p;
-    t.s3 = s->st[k][3].p;
-    t.s4 = s->st[k][4].p;
+    t.s0 = pp.st[k][0].p;
+    t.s1 = pp.st[k][1].p;
+    t.s2 = pp.st[k][2].p;
+    t.s3 = pp.st[k][3].p;
+    t.s4 = pp.st[k][4].p;
     return t;
   };
   WfArgs a;
@@ -317,17 +337,17 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
   a.n_blocks = nb;
   a.frame_first = frame_first;
   a.n_slots = (uint32_t)n_slots;
-  a.samples = s->samples.p;
+  a.samples = pp.samples.p;
   a.counters = s->counters.p;
-  a.hits = s->hits2[1].p;
-  a.hits_out = reinterpret_cast<unsigned long long*>(s->hits2[0].p);
+  a.hits = pp.hits2[1].p;
+  a.hits_out = reinterpret_cast<unsigned long long*>(pp.hits2[0].p);
   // raygen -> queue 0
   a.rq_in = queue(1);
   a.rq_out = queue(0);
   a.st_in = state(1);
   a.st_out = state(0);
-  a.n_in = s->qcounts.p;
-  a.n_out = s->qcounts.p;
+  a.n_in = pp.qcounts.p;
+  a.n_out = pp.qcounts.p;
   a.bounce = 0;
   a.scatter = 1u;
   if (s->tune.scatter) { // multiplier near 0.618 * n_sub, coprime to n_sub
@@ -345,9 +365,9 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
     while (gcd(m, n_sub) != 1u) m++;
     a.scatter = m % n_sub ? m % n_sub : 1u;
   }
-  HIP_TRY(s->sobol_tab.ensure((size_t)nf * 8));
-  a.sobol_tab = s->sobol_tab.p;
-  hipLaunchKernelGGL(sobol_kernel, dim3((unsigned)((nf * 8 + 255) / 256)), dim3(256), 0, st, frame_first + 1u, (int)nf, 8, s->sobol_tab.p);
+  HIP_TRY(pp.sobol_tab.ensure((size_t)nf * 8));
+  a.sobol_tab = pp.sobol_tab.p;
+  hipLaunchKernelGGL(sobol_kernel, dim3((unsigned)((nf * 8 + 255) / 256)), dim3(256), 0, st, frame_first + 1u, (int)nf, 8, pp.sobol_tab.p);
   hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((n_slots + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, a);
 
   const size_t lds = stack_lds_bytes(s);
@@ -378,32 +398,32 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
     TraceQArgs t;
     t.sc = a.sc;
     t.rq = queue(in);
-    t.hits = s->hits2[in].p;
-    t.n_paths = s->qcounts.p + b;
+    t.hits = pp.hits2[in].p;
+    t.n_paths = pp.qcounts.p + b;
     t.rays_per_path = (mis && b > 0) ? 2u : 1u;
     t.const_origin = b == 0 ? 1u : 0u;
     t.origin[0] = p->eye[0];
     t.origin[1] = p->eye[1];
     t.origin[2] = p->eye[2];
-    t.head = s->qcounts.p + 64 + b;
+    t.head = pp.qcounts.p + 64 + b;
     t.counters = s->counters.p;
     t.leaf_threshold = leaf_thr;
     t.pool_div = (uint32_t)pool_div;
     t.pool_max = (uint32_t)pool_max;
     t.stack_entries = (int32_t)(lds / (BLOCK * sizeof(int)));
     t.lds_nodes = lds_nodes;
-    t.dbg = debug_stages ? (s->qcounts.p + 100 + 4 * (b & 3)) : nullptr;
+    t.dbg = debug_stages ? (pp.qcounts.p + 100 + 4 * (b & 3)) : nullptr;
     t.slot_map = nullptr;
     t.steal = tu.steal ? 1u : 0u;
     t.count_rays = 1u;
-    t.redo_count = s->qcounts.p + 128 + b;
-    t.redo_slots = s->redo_slots.p;
-    t.redo_flag = s->redo_flag.p;
+    t.redo_count = pp.qcounts.p + 128 + b;
+    t.redo_slots = pp.redo_slots.p;
+    t.redo_flag = pp.redo_flag.p;
     t.wave_log = nullptr;
     if (debug_stages >= 2) {
-      HIP_TRY(s->wave_log.ensure((size_t)trace_grid_full * (BLOCK / 64) * 4));
-      HIP_TRY(hipMemsetAsync(s->wave_log.p, 0, (size_t)trace_grid_full * (BLOCK / 64) * 4 * sizeof(unsigned long long), st));
-      t.wave_log = s->wave_log.p;
+      HIP_TRY(pp.wave_log.ensure((size_t)trace_grid_full * (BLOCK / 64) * 4));
+      HIP_TRY(hipMemsetAsync(pp.wave_log.p, 0, (size_t)trace_grid_full * (BLOCK / 64) * 4 * sizeof(unsigned long long), st));
+      t.wave_log = pp.wave_log.p;
     }
     auto launch_traceq = [&](const TraceQArgs& q, bool small = false) {
       const unsigned trace_grid = small ? 64u : trace_grid_full; // redo lists are (nearly) empty
@@ -424,25 +444,25 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
       k.inner = s->inner.p;
       k.root_ref = s->root_ref;
       k.rq = queue(in);
-      k.hits = s->hits2[in].p;
+      k.hits = pp.hits2[in].p;
       k.n_rays = (uint32_t)n_slots;
       k.counters = s->counters.p;
-      k.redo_count = s->qcounts.p + 120;
-      k.redo_slots = s->redo_slots.p;
+      k.redo_count = pp.qcounts.p + 120;
+      k.redo_slots = pp.redo_slots.p;
       k.stack_entries = s->depth + 1;
       k.budget = packet_budget;
       k.origin[0] = p->eye[0];
       k.origin[1] = p->eye[1];
       k.origin[2] = p->eye[2];
-      k.dbg = debug_stages ? (s->qcounts.p + 116) : nullptr;
+      k.dbg = debug_stages ? (pp.qcounts.p + 116) : nullptr;
       const size_t lds_pk = (size_t)(BLOCK / 64) * k.stack_entries * 3 * sizeof(int);
       unsigned pk_grid = (unsigned)(s->num_cus * 7); // 66 VGPRs: 7 waves/SIMD = 7 workgroups of 4 waves per CU
       if ((size_t)pk_grid * BLOCK > n_slots) pk_grid = (unsigned)((n_slots + BLOCK - 1) / BLOCK);
       hipLaunchKernelGGL(tracepk_kernel, dim3(pk_grid), dim3(BLOCK), lds_pk, st, k);
       s->n_trace_launches++;
-      t.slot_map = s->redo_slots.p;
-      t.n_paths = s->qcounts.p + 120;
-      t.head = s->qcounts.p + 121;
+      t.slot_map = pp.redo_slots.p;
+      t.n_paths = pp.qcounts.p + 120;
+      t.head = pp.qcounts.p + 121;
       t.rays_per_path = 1u;
       t.steal = 0u;
       t.redo_flag = nullptr;
@@ -453,10 +473,10 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
         TraceQArgs r = t;
         r.steal = 0u;
         r.count_rays = 0u;
-        r.slot_map = s->redo_slots.p;
-        r.n_paths = s->qcounts.p + 128 + b;
+        r.slot_map = pp.redo_slots.p;
+        r.n_paths = pp.qcounts.p + 128 + b;
         r.rays_per_path = 1u;
-        r.head = s->qcounts.p + 192 + b;
+        r.head = pp.qcounts.p + 192 + b;
         r.dbg = nullptr;
         r.wave_log = nullptr;
         launch_traceq(r, true);
@@ -466,31 +486,31 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
       HIP_TRY(hipEventRecord(s->ev_trace[e][1], st));
       s->n_trace_events++;
     }
-    a.hits = s->hits2[in].p;
-    a.hits_out = reinterpret_cast<unsigned long long*>(s->hits2[out].p);
+    a.hits = pp.hits2[in].p;
+    a.hits_out = reinterpret_cast<unsigned long long*>(pp.hits2[out].p);
     a.rq_in = queue(in);
     a.rq_out = queue(out);
     a.st_in = state(in);
     a.st_out = state(out);
-    a.n_in = s->qcounts.p + b;
-    a.n_out = s->qcounts.p + b + 1;
+    a.n_in = pp.qcounts.p + b;
+    a.n_out = pp.qcounts.p + b + 1;
     a.bounce = b;
     launch_shade(a, full, dim3(shade_grid), st);
     if (debug_stages) { // diagnostic only: per-stage queue sizes and counters (synchronises)
       uint32_t q[2] = {0, 0};
       unsigned long long c[EZRT_CTR_COUNT];
       HIP_TRY(hipStreamSynchronize(st));
-      HIP_TRY(hipMemcpy(q, s->qcounts.p + b, sizeof q, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(q, pp.qcounts.p + b, sizeof q, hipMemcpyDeviceToHost));
       HIP_TRY(hipMemcpy(c, s->counters.p, sizeof c, hipMemcpyDeviceToHost));
       if (b == 0 && use_packet && !full) {
         uint32_t pk[3] = {0, 0, 0};
-        HIP_TRY(hipMemcpy(pk, s->qcounts.p + 116, sizeof pk, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(pk, pp.qcounts.p + 116, sizeof pk, hipMemcpyDeviceToHost));
         fprintf(stderr, "[ezrt] packet stage: wave inner steps %u, wave triangle steps %u, max steps of one wave %u\n", pk[0], pk[1], pk[2]);
       }
       if (debug_stages >= 2 && t.wave_log) { // per-wave life times of this stage's traceq launch
         const size_t nw = (size_t)trace_grid_full * (BLOCK / 64);
         std::vector<unsigned long long> w(nw * 4);
-        HIP_TRY(hipMemcpy(w.data(), s->wave_log.p, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(w.data(), pp.wave_log.p, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         unsigned long long t0 = ~0ull;
         for (size_t i = 0; i < nw; i++)
           if (w[i * 4] && w[i * 4] < t0) t0 = w[i * 4];
@@ -514,8 +534,8 @@ int wavefront_chunk(EzrtScene* s, const EzrtRenderParams* p, int nb, uint32_t fr
                 pct(rays, 1.0));
       }
       uint32_t dbg[3] = {0, 0, 0};
-      HIP_TRY(hipMemcpy(dbg, s->qcounts.p + 100 + 4 * (b & 3), sizeof dbg, hipMemcpyDeviceToHost));
-      HIP_TRY(hipMemset(s->qcounts.p + 100 + 4 * (b & 3), 0, sizeof dbg));
+      HIP_TRY(hipMemcpy(dbg, pp.qcounts.p + 100 + 4 * (b & 3), sizeof dbg, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemset(pp.qcounts.p + 100 + 4 * (b & 3), 0, sizeof dbg));
       fprintf(stderr, "[ezrt] stage %d: paths_in %u paths_out %u | cum rays %llu pops %llu inner %llu tris %llu | max/ray pops %u tris %u iters %u\n", b, q[0],
               q[1], c[0], c[1], c[2], c[3], dbg[0], dbg[1], dbg[2]);
     }
@@ -667,6 +687,11 @@ void ezrt_scene_destroy(EzrtScene* s) {
   if (s->ev_begin) {
     (void)hipEventDestroy(s->ev_begin);
     (void)hipEventDestroy(s->ev_end);
+    for (Pipe& q : s->pipe) {
+      if (q.stream) (void)hipStreamDestroy(q.stream);
+      if (q.ev_done) (void)hipEventDestroy(q.ev_done);
+      if (q.ev_free) (void)hipEventDestroy(q.ev_free);
+    }
     for (int i = 0; i < MAX_TRACE_EVENTS; i++) {
       (void)hipEventDestroy(s->ev_trace[i][0]);
       (void)hipEventDestroy(s->ev_trace[i][1]);
@@ -717,11 +742,24 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
     size_t chunk = (size_t)(16u << 20) / per_frame;
     if (chunk < 1) chunk = 1;
     if (chunk > p->spp) chunk = p->spp;
-    HIP_TRY(s->samples.ensure(per_frame * chunk));
     const int use_mega = s->tune.megakernel;
+    // pipelined: the call's frames in sub-chunks that alternate between the two pipes (own streams)
+    int n_pipes = (!use_mega && s->tune.pipes >= 2 && p->spp >= 2 && !s->tune.debug_stages) ? 2 : 1;
+    if (n_pipes == 2) {
+      size_t half = (p->spp + 1) / 2;
+      if (s->tune.sub_frames > 0 && (size_t)s->tune.sub_frames < half) half = (size_t)s->tune.sub_frames;
+      if (chunk > half) chunk = half;
+    }
     const size_t lds = stack_lds_bytes(s);
-    for (uint32_t done = 0; done < p->spp;) {
+    uint32_t k = 0;
+    for (uint32_t done = 0; done < p->spp; k++) {
       uint32_t nf = (uint32_t)((p->spp - done < chunk) ? (p->spp - done) : chunk);
+      Pipe& q = s->pipe[n_pipes == 2 ? (k & 1u) : 0u];
+      hipStream_t qs = n_pipes == 2 ? q.stream : st;
+      HIP_TRY(q.samples.ensure(per_frame * chunk));
+      if (n_pipes == 2) { // after everything queued before the call and after this pipe's previous sub-chunk was consumed
+        HIP_TRY(hipStreamWaitEvent(qs, k < 2 ? s->ev_begin : q.ev_free, 0));
+      }
       if (use_mega) {
         TraceArgs a;
         a.sc = s->dev();
@@ -729,7 +767,7 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
         a.blocks = s->blocks.p;
         a.n_blocks = nb;
         a.frame_first = p->frame0 + done;
-        a.samples = s->samples.p;
+        a.samples = q.samples.p;
         a.counters = s->counters.p;
         a.log_tri = nullptr;
         a.log_t = nullptr;
@@ -744,8 +782,12 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
         }
         s->n_trace_launches++;
       } else {
-        rc = wavefront_chunk(s, p, nb, p->frame0 + done, nf, st);
+        rc = wavefront_chunk(s, q, p, nb, p->frame0 + done, nf, qs);
         if (rc) return rc;
+      }
+      if (n_pipes == 2) { // the running mean is applied in frame order, on the caller's stream
+        HIP_TRY(hipEventRecord(q.ev_done, qs));
+        HIP_TRY(hipStreamWaitEvent(st, q.ev_done, 0));
       }
       AccumArgs b;
       b.p = *p;
@@ -753,9 +795,10 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
       b.n_blocks = nb;
       b.frame_first = p->frame0 + done;
       b.n_frames = nf;
-      b.samples = s->samples.p;
+      b.samples = q.samples.p;
       b.accum = reinterpret_cast<float4*>(accum_dev);
       hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, st, b);
+      if (n_pipes == 2) HIP_TRY(hipEventRecord(q.ev_free, st));
       done += nf;
     }
     HIP_TRY(hipGetLastError());
