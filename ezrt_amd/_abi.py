@@ -89,6 +89,13 @@ HOST_ABI = {
 }
 
 
+# GPU scene-build entry points of libezrt_hip.so only (include/ezrt_build.h)
+BUILD_ABI = {
+    "ezrt_build_lbvh": (C.c_int, [c_float_p, C.c_int, C.c_int, c_float_p, c_float_p, C.c_int, C.POINTER(C.c_int),
+                                  c_float_p]),
+}
+
+
 def _declare(lib, table):
     for name, (res, args) in table.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
@@ -119,7 +126,7 @@ def load_hip():
             raise RuntimeError(
                 "ezrt_amd: %s is missing -- build it with `make hip` (or __graft_entry__.build()); "
                 "there is no CPU fallback for the trace" % path)
-        _hip = declare_trace_abi(C.CDLL(path))
+        _hip = _declare(declare_trace_abi(C.CDLL(path)), BUILD_ABI)
     return _hip
 
 

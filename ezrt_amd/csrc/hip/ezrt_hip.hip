@@ -548,6 +548,8 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
 extern "C" {
 
 const char* ezrt_last_error(void) { return g_err; }
+// for the other translation units of this library (ezrt_lbvh.hip)
+__attribute__((visibility("hidden"))) int ezrt_fail_msg(int code, const char* msg) { return fail(code, "%s", msg); }
 const char* ezrt_backend(void) { return "hip:gfx950"; }
 
 int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nodes, EzrtScene** out) {

@@ -57,3 +57,11 @@ def test_product_has_no_oracle_dependency():
                 if "libezrt_oracle" in txt or "oracle/" in txt.replace("the oracle/", ""):
                     bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_hip_library_exports_the_gpu_build_entry_points(hip):
+    from ezrt_amd import _abi
+    names = _declared("ezrt_build.h")
+    assert names and set(names) == set(_abi.BUILD_ABI)
+    for n in names:
+        assert hasattr(hip.lib, n), n
