@@ -283,6 +283,10 @@ extern "C" int ezrt_build_lbvh(const float* tri, int n_tri, int leaf_n, float* t
   LB_TRY(d_size.alloc(2 * (size_t)n));
   LB_TRY(d_box.alloc(2 * (size_t)n * 6));
   LB_TRY(d_arrived.alloc(n));
+  LB_TRY(d_nodes.alloc(2 * (size_t)n * EZRT_NODE_FLOATS));
+  size_t tmp_bytes = 0;
+  LB_TRY(rocprim::radix_sort_keys(nullptr, tmp_bytes, d_keys.p, d_keys2.p, (size_t)n, 0, 62, nullptr));
+  LB_TRY(d_tmp.alloc(tmp_bytes));
   LB_TRY(hipMemcpy(d_tri.p, tri, tri_bytes, hipMemcpyHostToDevice));
   hipEvent_t e0, e1;
   LB_TRY(hipEventCreate(&e0));
@@ -294,9 +298,6 @@ extern "C" int ezrt_build_lbvh(const float* tri, int n_tri, int leaf_n, float* t
   const int grid_n = (n + TPB - 1) / TPB;
   hipLaunchKernelGGL(k_centroid_bounds, dim3(grid_n < 1024 ? grid_n : 1024), dim3(TPB), 0, nullptr, d_tri.p, n, d_ord.p);
   hipLaunchKernelGGL(k_morton, dim3(grid_n), dim3(TPB), 0, nullptr, d_tri.p, n, d_ord.p, d_keys.p);
-  size_t tmp_bytes = 0;
-  LB_TRY(rocprim::radix_sort_keys(nullptr, tmp_bytes, d_keys.p, d_keys2.p, (size_t)n, 0, 62, nullptr));
-  LB_TRY(d_tmp.alloc(tmp_bytes));
   LB_TRY(rocprim::radix_sort_keys(d_tmp.p, tmp_bytes, d_keys.p, d_keys2.p, (size_t)n, 0, 62, nullptr));
 
   int total_nodes = 2; // dummy + root
@@ -321,17 +322,6 @@ extern "C" int ezrt_build_lbvh(const float* tri, int n_tri, int leaf_n, float* t
   LB_TRY(hipMemsetAsync(d_arrived.p, 0, (size_t)n * sizeof(uint32_t), nullptr));
   const int grid_2n = (2 * n - 1 + TPB - 1) / TPB;
   hipLaunchKernelGGL(k_fit, dim3(grid_2n), dim3(TPB), 0, nullptr, f);
-  int root_size = 0;
-  const int root_node = n > 1 ? 0 : 0; // node 0 is the root for n > 1; for n == 1 the only key-leaf is node 0 too
-  LB_TRY(hipMemcpy(&root_size, d_size.p + root_node, sizeof(int), hipMemcpyDeviceToHost));
-  total_nodes = 1 + root_size;
-  if (total_nodes > nodes_capacity) {
-    char buf[128];
-    snprintf(buf, sizeof buf, "nodes_capacity %d too small: the tree has %d nodes", nodes_capacity, total_nodes);
-    return ezrt_fail_msg(EZRT_ERR_INVALID, buf);
-  }
-  LB_TRY(d_nodes.alloc((size_t)total_nodes * EZRT_NODE_FLOATS));
-  LB_TRY(hipMemsetAsync(d_nodes.p, 0, (size_t)total_nodes * EZRT_NODE_FLOATS * sizeof(float), nullptr));
   hipLaunchKernelGGL(k_emit, dim3(grid_2n), dim3(TPB), 0, nullptr, f, d_nodes.p);
   hipLaunchKernelGGL(k_gather, dim3((unsigned)(((size_t)n * 9 + TPB - 1) / TPB)), dim3(TPB), 0, nullptr,
                      reinterpret_cast<const float4*>(d_tri.p), d_keys2.p, n, reinterpret_cast<float4*>(d_tri_out.p));
@@ -342,6 +332,14 @@ extern "C" int ezrt_build_lbvh(const float* tri, int n_tri, int leaf_n, float* t
   LB_TRY(hipEventElapsedTime(&ms, e0, e1));
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  int root_size = 0; // the root is node 0 of the radix tree (for n == 1 the only key-leaf is node 0 too)
+  LB_TRY(hipMemcpy(&root_size, d_size.p, sizeof(int), hipMemcpyDeviceToHost));
+  total_nodes = 1 + root_size;
+  if (total_nodes > nodes_capacity) {
+    char buf[128];
+    snprintf(buf, sizeof buf, "nodes_capacity %d too small: the tree has %d nodes", nodes_capacity, total_nodes);
+    return ezrt_fail_msg(EZRT_ERR_INVALID, buf);
+  }
   LB_TRY(hipMemcpy(tri_out, d_tri_out.p, tri_bytes, hipMemcpyDeviceToHost));
   LB_TRY(hipMemcpy(nodes_out, d_nodes.p, (size_t)total_nodes * EZRT_NODE_FLOATS * sizeof(float), hipMemcpyDeviceToHost));
   // node 0: the reference's testNode sentinel (P3/main.cpp:707-713), as ezrt::testNode() encodes it
