@@ -4,18 +4,15 @@
 // ~18 % of VALU lanes active (dead paths, wildly different traversal lengths) and ~48 % of wave
 // time parked on memory at 4 waves/SIMD.  Here a frame chunk is processed as queues:
 //
-//   raygen_kernel      one thread per pixel-sample: primary ray -> ray queue 0, RNG state
-//   traceq_kernel      PERSISTENT hitBVH over a ray queue.  Lanes pull rays one at a time: a lane
-//                      whose ray is finished takes the ray it prefetched while traversing and
-//                      prefetches the next, so a wave never idles behind its slowest ray.  Inner
-//                      nodes are stepped every iteration; leaves are postponed until enough lanes
-//                      wait at a leaf (ballot), so the triangle loop runs with a well-filled exec
-//                      mask.  Carries {t, tri} only: ~64 VGPRs => 8 waves/SIMD to hide L2 latency.
-//                      Traversal stack per lane in LDS.
+//   raygen_kernel      one thread per pixel-sample: primary ray direction -> ray queue 0, in a
+//                      scattered 8x8 sub-block order (queue_to_sample)
+//   traceq_kernel      PERSISTENT hitBVH over a ray queue (ezrt_traceq.h): per-lane ray refill,
+//                      LDS traversal stack + LDS-resident top of the tree, postponed cooperative
+//                      leaves, intra-wave work stealing.  Carries {t, tri} only.
 //   shade_kernel<I>    consumes the hits of bounce b-1, terminates paths into the sample buffer,
 //                      starts bounce b (Sobol/CP or rand sampling, Disney BRDF, env lookups) and
-//                      COMPACTS survivors into the next queue with one wave-level ballot + one
-//                      atomic per wave -- lanes stay converged across bounces.
+//                      COMPACTS survivors into the next queue with one ballot per wave + one atomic
+//                      per workgroup -- lanes stay converged across bounces.
 //
 // Per path the arithmetic and its order are exactly the megakernel's (= the oracle's): only the
 // schedule changes.  Queue order is non-deterministic, results are not (every path owns its sample
