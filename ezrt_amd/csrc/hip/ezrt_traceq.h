@@ -20,6 +20,7 @@
 
 namespace ezd {
 
+constexpr uint32_t REF_NONE = 0xffffffffu; // a lane without a ray (every predicate below is ONE compare on `ref`)
 constexpr uint32_t TRACE_POOL_MIN = 8; // smallest reservation: short queues are spread over every wave
 
 struct RayQueue {
@@ -94,7 +95,6 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
   uint32_t nx_slot = 0;
   float4 nx_o = make_float4(0, 0, 0, 0), nx_d = make_float4(0, 0, 0, 0);
 
-  bool work = false; // current ray
   bool wild = false; // ... needs the exact NaN-aware slab test
   uint32_t slot = 0;
   f3 S = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
   int sp = 0, sb = 0; // live stack entries are rows [sb, sp): the owner pops at sp, thieves take row sb
   bool tie = false;    // two contributors published the same best distance for different triangles
   bool shared = false; // this lane's ray has been split: other lanes hold subtrees of it (or this lane is a thief)
-  uint32_t ref = 0;
+  uint32_t ref = REF_NONE; // current node: inner record index (bit 31 clear), leaf ref (bit 31 set), or REF_NONE
   Counters ctr = {0, 0, 0, 0, 0, 0, 0};
   uint32_t ray_p0 = 0, ray_t0 = 0, ray_i0 = 0, iters = 0;
   unsigned long long* hits64 = reinterpret_cast<unsigned long long*>(a.hits);
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
     } else {
       a.hits[slot] = make_int2(best_tri, __float_as_int(best_t));
     }
-    work = false;
+    ref = REF_NONE;
     tie = false;
     shared = false;
     sp = 0;
@@ -138,12 +138,11 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
     if (FULLCTR) iters++;
     wave_iters++;
     // ---- refill: lanes without work adopt their prefetched ray, then prefetch another
-    const bool want = !work;
+    const bool want = ref == REF_NONE;
     if (ballot(want)) {
       if (want && nx_valid) {
         nx_valid = false;
         if (nx_d.w != 0.0f) {
-          work = true;
           slot = nx_slot;
           S = mk(nx_o.x, nx_o.y, nx_o.z);
           d = mk(nx_d.x, nx_d.y, nx_d.z);
@@ -203,14 +202,14 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
         }
       }
     }
-    if (!ballot(work || nx_valid)) break;
+    if (!ballot(ref != REF_NONE || nx_valid)) break;
 
     // ---- work stealing: lanes with nothing left to fetch take the oldest pending subtree of a busy lane
     if (a.steal) {
-      const bool idle = !work && !nx_valid;
+      const bool idle = ref == REF_NONE && !nx_valid;
       const unsigned long long im = ballot(idle);
       if (im) {
-        const bool rich = work && (sp - sb) >= 1;
+        const bool rich = sp > sb; // (sp == sb == 0 without a ray)
         const unsigned long long vm = ballot(rich);
         if (vm) {
           const int ni = (int)__popcll(im), nv = (int)__popcll(vm);
@@ -236,7 +235,6 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
           const float vdx = __shfl(d.x, src, 64), vdy = __shfl(d.y, src, 64), vdz = __shfl(d.z, src, 64);
           const int vwild = __shfl((int)wild, src, 64);
           if (thief) {
-            work = true;
             shared = true;
             slot = vslot;
             S = mk(vsx, vsy, vsz);
@@ -260,7 +258,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
     }
 
     // ---- inner step for every lane standing on an inner node (P5/fsh:277-302)
-    const bool at_inner = work && !(ref & LEAF_BIT);
+    const bool at_inner = (int32_t)ref >= 0;
     if (at_inner) {
       if (FULLCTR) ctr.inner++;
       float4 q0, q1, q2, q3;
@@ -311,11 +309,11 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
     // ---- leaf phase (hitArray, P5/fsh:238-251): postponed until enough lanes wait at a leaf, or
     // nobody can step.  (Issuing the node and triangle fetches of one iteration together was tried:
     // +22 VGPRs cost a wave per SIMD and 10 % -- see DESIGN.md.)
-    const bool at_leaf = work && (ref & LEAF_BIT);
+    const bool at_leaf = (int32_t)ref < -1; // bit 31 set, not REF_NONE
     const unsigned long long lm = ballot(at_leaf);
     if (lm) {
       const int Lc = (int)__popcll(lm);
-      const bool go = Lc >= a.leaf_threshold || !ballot(work && !(ref & LEAF_BIT));
+      const bool go = Lc >= a.leaf_threshold || !ballot((int32_t)ref >= 0);
       if (go) {
         if (!FULLCTR && Lc <= 32) {
           // cooperative: g = 64 / Lc lanes (power of two) per waiting ray
