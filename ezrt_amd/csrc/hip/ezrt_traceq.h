@@ -91,8 +91,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
   uint32_t pool_end = pool_next + pool_size;
   bool exhausted = false;               // wave-uniform: nothing left to reserve
 
-  bool nx_valid = false; // prefetched next ray of this lane
-  uint32_t nx_slot = 0;
+  uint32_t nx_slot = REF_NONE; // prefetched next ray of this lane (REF_NONE: none)
   float4 nx_o = make_float4(0, 0, 0, 0), nx_d = make_float4(0, 0, 0, 0);
 
   bool wild = false; // ... needs the exact NaN-aware slab test
@@ -140,10 +139,11 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
     // ---- refill: lanes without work adopt their prefetched ray, then prefetch another
     const bool want = ref == REF_NONE;
     if (ballot(want)) {
-      if (want && nx_valid) {
-        nx_valid = false;
+      if (want && nx_slot != REF_NONE) {
+        const uint32_t adopted = nx_slot;
+        nx_slot = REF_NONE;
         if (nx_d.w != 0.0f) {
-          slot = nx_slot;
+          slot = adopted;
           S = mk(nx_o.x, nx_o.y, nx_o.z);
           d = mk(nx_d.x, nx_d.y, nx_d.z);
           inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
           }
         }
       }
-      const bool need = !nx_valid && !exhausted;
+      const bool need = nx_slot == REF_NONE && !exhausted;
       const unsigned long long m = ballot(need);
       if (m) {
         const uint32_t cnt = (uint32_t)__popcll(m);
@@ -198,15 +198,14 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
           nx_slot = rs;
           nx_o = a.const_origin ? make_float4(a.origin[0], a.origin[1], a.origin[2], 0.0f) : a.rq.o[rs];
           nx_d = a.rq.d[rs];
-          nx_valid = true;
         }
       }
     }
-    if (!ballot(ref != REF_NONE || nx_valid)) break;
+    if (!ballot((ref & nx_slot) != REF_NONE)) break; // no lane has a ray or a prefetched one
 
     // ---- work stealing: lanes with nothing left to fetch take the oldest pending subtree of a busy lane
     if (a.steal) {
-      const bool idle = ref == REF_NONE && !nx_valid;
+      const bool idle = (ref & nx_slot) == REF_NONE;
       const unsigned long long im = ballot(idle);
       if (im) {
         const bool rich = sp > sb; // (sp == sb == 0 without a ray)
