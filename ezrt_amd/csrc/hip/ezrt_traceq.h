@@ -39,6 +39,7 @@ struct TraceQArgs {
   uint32_t* head;          // queue head (device, zeroed per launch)
   unsigned long long* counters;
   int32_t leaf_threshold;  // lanes waiting at a leaf that trigger the triangle phase
+  uint32_t static_pct;     // share of the queue dealt statically (first pool of every wave), percent
   uint32_t pool_div, pool_max; // pool = clamp(n_rays / (n_waves * pool_div), 8, pool_max)
   int32_t lds_nodes;       // inner records [0, lds_nodes) staged in LDS (after stack + lane table)
   int32_t stack_entries;   // LDS stack rows (tree depth); the per-wave lane table follows them
@@ -86,9 +87,12 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
   // launch's tail is made of waves that drew an expensive pool well before the end.)
   uint32_t pool_size = (n_rays + n_waves * a.pool_div - 1) / (n_waves * a.pool_div);
   pool_size = pool_size > a.pool_max ? a.pool_max : (pool_size < TRACE_POOL_MIN ? TRACE_POOL_MIN : pool_size);
-  const uint32_t static_total = n_waves * pool_size;
-  uint32_t pool_next = (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * pool_size; // wave-uniform pool of ray indices
-  uint32_t pool_end = pool_next + pool_size;
+  // (the static share can be larger than one dynamic pool: `static_pct` % of the queue)
+  uint32_t static_pool = (uint32_t)(((unsigned long long)n_rays * a.static_pct) / (100ull * n_waves));
+  static_pool = static_pool < pool_size ? pool_size : static_pool;
+  const uint32_t static_total = n_waves * static_pool;
+  uint32_t pool_next = (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * static_pool; // wave-uniform pool of ray indices
+  uint32_t pool_end = pool_next + static_pool;
   bool exhausted = false;               // wave-uniform: nothing left to reserve
 
   uint32_t nx_slot = REF_NONE; // prefetched next ray of this lane (REF_NONE: none)
