@@ -229,12 +229,25 @@ def main():
                                              % (n_total, W, H, cr, d_total)}
             if linf is not None:
                 out["cpu_baseline"]["linf_vs_gpu"] = linf
+            # per-core figure: one more frame on ONE thread
+            try:
+                gomp = ctypes.CDLL("libgomp.so.1")
+                gomp.omp_set_num_threads(1)
+                so.counters_reset()
+                t1 = time.perf_counter()
+                so.render(trace.make_params(W, H, eye, cam, args.integrator, args.bounces, spp=1, frame0=args.spp),
+                          img.copy())
+                d1t = time.perf_counter() - t1
+                out["cpu_baseline"]["one_thread_Mrays_s"] = round(so.counters()["rays"] / d1t / 1e6, 4)
+                gomp.omp_set_num_threads(cores)
+            except OSError:
+                pass
 
     if rank == 0:
         if args.save_png:
-            from PIL import Image
-            rgb = hip.tonemap(final.detach().cpu().numpy().reshape(-1, 4)).reshape(H, W, 3)[::-1]
-            Image.fromarray(rgb).save(args.save_png)
+            from ezrt_amd import imageio
+            rgb = hip.tonemap(final.detach().cpu().numpy().reshape(-1, 4)).reshape(H, W, 3)
+            imageio.write_png(args.save_png, rgb)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -78,21 +78,22 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
   __syncthreads();
 
   const uint32_t n_waves = gridDim.x * (BLOCK / 64);
-  // Queue indices are handed out in pools of `pool_size`.  The first pool of every wave is static
-  // (wave w owns [w * pool_size, (w + 1) * pool_size)): no atomic at all for queues of up to
-  // n_waves * pool_max rays -- 5120 waves bumping one counter would cost ~60 us per round, the whole
-  // budget of a late bounce (one word sustains ~88 atomics/us chip-wide).  Indices beyond the static
-  // region are reserved dynamically, one atomic per pool.  (Smaller pools for the queue's last
-  // stretch, and eight interleaved counters with guided pool sizes, were tried: no gain -- the
-  // launch's tail is made of waves that drew an expensive pool well before the end.)
+  // Queue indices are handed out in pools of `pool_size`.  The first `static_rounds` pools of every
+  // wave are static and interleaved (round k: wave w owns pool k * n_waves + w): no atomic at all for
+  // queues of up to n_waves * pool_max rays -- 5120 waves bumping one counter would cost ~60 us per
+  // round, the whole budget of a late bounce (one word sustains ~88 atomics/us chip-wide) -- and,
+  // with the blocks of a frame queued most-expensive-first, every wave gets the same mix of expensive
+  // and cheap pools.  Indices beyond the static region are reserved dynamically, one atomic per pool.
+  // (Smaller pools for the queue's last stretch, and eight interleaved counters with guided pool
+  // sizes, were tried: no gain.)
   uint32_t pool_size = (n_rays + n_waves * a.pool_div - 1) / (n_waves * a.pool_div);
   pool_size = pool_size > a.pool_max ? a.pool_max : (pool_size < TRACE_POOL_MIN ? TRACE_POOL_MIN : pool_size);
-  // (the static share can be larger than one dynamic pool: `static_pct` % of the queue)
-  uint32_t static_pool = (uint32_t)(((unsigned long long)n_rays * a.static_pct) / (100ull * n_waves));
-  static_pool = static_pool < pool_size ? pool_size : static_pool;
-  const uint32_t static_total = n_waves * static_pool;
-  uint32_t pool_next = (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * static_pool; // wave-uniform pool of ray indices
-  uint32_t pool_end = pool_next + static_pool;
+  uint32_t static_rounds = (uint32_t)(((unsigned long long)n_rays * a.static_pct) / (100ull * n_waves * pool_size));
+  static_rounds = static_rounds < 1u ? 1u : static_rounds;
+  const uint32_t static_total = static_rounds * n_waves * pool_size;
+  const uint32_t wave_id = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+  uint32_t round = 0;
+  uint32_t pool_next = 0, pool_end = 0; // wave-uniform pool of ray indices
   bool exhausted = false;               // wave-uniform: nothing left to reserve
 
   uint32_t nx_slot = REF_NONE; // prefetched next ray of this lane (REF_NONE: none)
@@ -175,7 +176,12 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
         bool served;
         if (pool_end - pool_next < cnt) { // wave-uniform: top the pool up with one atomic
           uint32_t base = n_rays; // (nothing beyond the static region: done)
-          if (static_total < n_rays) {
+          if (round < static_rounds) {
+            // (rotated per round: n_waves is often a multiple of the blocks per frame, and a wave must not
+            // meet the same block of every frame)
+            base = (round * n_waves + (wave_id + round * 1223u) % n_waves) * pool_size;
+            round++;
+          } else if (static_total < n_rays) {
             if (lane == 0) base = atomicAdd(a.head, pool_size);
             base = static_total + __shfl(base, 0, 64);
           }
