@@ -351,8 +351,10 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
   a.n_out = pp.qcounts.p;
   a.bounce = 0;
   a.scatter = 1u;
+  a.scatter_shift = 6u;
   if (s->tune.scatter) { // multiplier near 0.618 * n_sub, coprime to n_sub
-    const uint32_t n_sub = (uint32_t)nb * 4u;
+    a.scatter_shift = (uint32_t)(s->tune.scatter >= 4 && s->tune.scatter <= 8 ? s->tune.scatter : 6); // 1: 8x8 sub-blocks
+    const uint32_t n_sub = ((uint32_t)nb * 256u) >> a.scatter_shift;
     auto gcd = [](uint32_t x, uint32_t y) {
       while (y) {
         const uint32_t t = x % y;

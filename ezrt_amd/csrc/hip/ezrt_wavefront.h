@@ -51,6 +51,7 @@ struct WfArgs {
   int32_t bounce;          // the bounce this stage starts (0 = consumes the primary hits)
   const float* sobol_tab;  // [frame - frame_first][8]: sobol(d, grayCode(frame + 1)), filled once per chunk
   uint32_t scatter;        // queue order of the primary rays: see queue_to_sample (1 = identity)
+  uint32_t scatter_shift;  // scattered granule = 1 << scatter_shift slots (6: 8x8 sub-block, 8: 16x16 block, 5: 8x4 pixels)
 };
 
 EZD void slot_to_pixel(const int2* blocks, int n_blocks, uint32_t slot, uint32_t frame_first, int& x, int& y,
@@ -71,12 +72,12 @@ EZD void slot_to_pixel(const int2* blocks, int n_blocks, uint32_t slot, uint32_t
 // that drew the expensive ones.  So the 8x8 sub-blocks of a frame are visited in a scattered
 // order, sub-block (r * scatter) mod n_sub at position r (scatter coprime to n_sub): a pool is four
 // sub-blocks from distant parts of the image and every pool costs about the same.
-EZD uint32_t queue_to_sample(uint32_t qslot, uint32_t n_blocks, uint32_t scatter) {
-  const uint32_t n_sub = n_blocks * 4u;
-  const uint32_t q = qslot >> 6;
+EZD uint32_t queue_to_sample(uint32_t qslot, uint32_t n_blocks, uint32_t scatter, uint32_t sh = 6u) {
+  const uint32_t n_sub = (n_blocks * 256u) >> sh; // granules of 1 << sh slots per frame
+  const uint32_t q = qslot >> sh;
   const uint32_t fk = q / n_sub, r = q - fk * n_sub;
   const uint32_t r2 = (uint32_t)(((unsigned long long)r * scatter) % n_sub);
-  return ((fk * n_sub + r2) << 6) | (qslot & 63u);
+  return ((fk * n_sub + r2) << sh) | (qslot & ((1u << sh) - 1u));
 }
 
 // ---------------------------------------------------------------------------
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(BLOCK) void raygen_kernel(WfArgs a) {
   if (slot == 0) *a.n_out = a.n_slots; // stage 0's path count, read by the first trace launch
   int x, y;
   uint32_t frame;
-  slot_to_pixel(a.blocks, a.n_blocks, queue_to_sample(slot, (uint32_t)a.n_blocks, a.scatter), a.frame_first, x, y, frame);
+  slot_to_pixel(a.blocks, a.n_blocks, queue_to_sample(slot, (uint32_t)a.n_blocks, a.scatter, a.scatter_shift), a.frame_first, x, y, frame);
   const EzrtRenderParams& p = a.p;
   if (!pixel_owned(p, x, y)) {
     a.rq_out.d[slot] = make_float4(0, 0, 0, 0.0f);
@@ -223,7 +224,7 @@ EZD bool shade_path(const WfArgs& a, const uint32_t i, bool live, Counters& ctr,
   f3 colour = mk(0, 0, 0);
   const f3 rd = mk(rd4.x, rd4.y, rd4.z);
   if (PASS == 0) {
-    sslot = queue_to_sample(i, (uint32_t)a.n_blocks, a.scatter);
+    sslot = queue_to_sample(i, (uint32_t)a.n_blocks, a.scatter, a.scatter_shift);
     if (rd4.w == 0.0f) {
       live = false; // pixel not owned by this shard
     } else {
