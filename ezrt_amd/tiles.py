@@ -59,11 +59,18 @@ class TilePlan:
     def unpack(self, packed_per_rank):
         """packed_per_rank[r] = what rank r packed -> the full frame."""
         first = packed_per_rank[0]
-        tiles = torch.zeros((self.n_tiles, self.tile_h, self.tile_w, first.shape[-1]), dtype=first.dtype,
+        key = ("all", str(first.device))
+        if key not in self._ids:  # (destination tile id, row of the concatenated payload) of every REAL entry
+            dst, src = [], []
+            for r in range(self.world):
+                ids, n_real = self.tile_ids(r, first.device)
+                dst.append(ids[:n_real])
+                src.append(torch.arange(n_real, dtype=torch.long, device=first.device) + r * self.per_rank)
+            self._ids[key] = (torch.cat(dst), torch.cat(src))
+        dst, src = self._ids[key]
+        tiles = torch.empty((self.n_tiles, self.tile_h, self.tile_w, first.shape[-1]), dtype=first.dtype,
                             device=first.device)
-        for r, packed in enumerate(packed_per_rank):
-            ids, n_real = self.tile_ids(r, first.device)
-            tiles[ids[:n_real]] = packed[:n_real]
+        tiles.index_copy_(0, dst, torch.cat(list(packed_per_rank)).index_select(0, src))
         return self.from_tiles(tiles)
 
 
