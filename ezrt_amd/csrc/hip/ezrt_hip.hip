@@ -425,8 +425,8 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     t.redo_flag = pp.redo_flag.p;
     t.wave_log = nullptr;
     if (debug_stages >= 2) {
-      HIP_TRY(pp.wave_log.ensure((size_t)trace_grid_full * (BLOCK / 64) * 4));
-      HIP_TRY(hipMemsetAsync(pp.wave_log.p, 0, (size_t)trace_grid_full * (BLOCK / 64) * 4 * sizeof(unsigned long long), st));
+      HIP_TRY(pp.wave_log.ensure((size_t)trace_grid_full * (BLOCK / 64) * 8));
+      HIP_TRY(hipMemsetAsync(pp.wave_log.p, 0, (size_t)trace_grid_full * (BLOCK / 64) * 8 * sizeof(unsigned long long), st));
       t.wave_log = pp.wave_log.p;
     }
     auto launch_traceq = [&](const TraceQArgs& q, bool small = false) {
@@ -513,19 +513,26 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
       }
       if (debug_stages >= 2 && t.wave_log) { // per-wave life times of this stage's traceq launch
         const size_t nw = (size_t)trace_grid_full * (BLOCK / 64);
-        std::vector<unsigned long long> w(nw * 4);
+        std::vector<unsigned long long> w(nw * 8);
         HIP_TRY(hipMemcpy(w.data(), pp.wave_log.p, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         unsigned long long t0 = ~0ull;
         for (size_t i = 0; i < nw; i++)
-          if (w[i * 4] && w[i * 4] < t0) t0 = w[i * 4];
+          if (w[i * 8] && w[i * 8] < t0) t0 = w[i * 8];
+        unsigned long long s_it = 0, s_is = 0, s_il = 0, s_ll = 0, s_lr = 0, s_busy = 0;
         std::vector<double> endt, life, its, rays, startt;
         for (size_t i = 0; i < nw; i++)
-          if (w[i * 4]) {
-            startt.push_back((double)(w[i * 4] - t0) * 0.01);
-            endt.push_back((double)(w[i * 4 + 1] - t0) * 0.01);
-            life.push_back((double)(w[i * 4 + 1] - w[i * 4]) * 0.01);
-            its.push_back((double)w[i * 4 + 2]);
-            rays.push_back((double)w[i * 4 + 3]);
+          if (w[i * 8]) {
+            startt.push_back((double)(w[i * 8] - t0) * 0.01);
+            endt.push_back((double)(w[i * 8 + 1] - t0) * 0.01);
+            life.push_back((double)(w[i * 8 + 1] - w[i * 8]) * 0.01);
+            its.push_back((double)(uint32_t)w[i * 8 + 2]);
+            rays.push_back((double)(uint32_t)w[i * 8 + 3]);
+            s_it += (uint32_t)w[i * 8 + 2];
+            s_is += w[i * 8 + 2] >> 32;
+            s_il += w[i * 8 + 3] >> 32;
+            s_ll += (uint32_t)w[i * 8 + 4];
+            s_lr += w[i * 8 + 4] >> 32;
+            s_busy += w[i * 8 + 5];
           }
         auto pct = [](std::vector<double>& v, double q) {
           if (v.empty()) return 0.0;
@@ -536,6 +543,9 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
                 endt.size(), pct(startt, 0.5), pct(startt, 1.0), pct(endt, 0.1), pct(endt, 0.5), pct(endt, 0.9), pct(endt, 0.99),
                 pct(endt, 1.0), pct(life, 0.5), pct(life, 1.0), pct(its, 0.5), pct(its, 0.99), pct(its, 1.0), pct(rays, 0.5),
                 pct(rays, 1.0));
+        fprintf(stderr, "[ezrt]   iterations %llu: lanes with a ray %.1f/64 | inner steps in %.0f %% of them, %.1f lanes each | cooperative leaf rounds in %.0f %%, %.1f rays each\n",
+                s_it, (double)s_busy / (double)(s_it ? s_it : 1), 100.0 * (double)s_is / (double)(s_it ? s_it : 1), (double)s_il / (double)(s_is ? s_is : 1),
+                100.0 * (double)s_lr / (double)(s_it ? s_it : 1), (double)s_ll / (double)(s_lr ? s_lr : 1));
       }
       uint32_t dbg[3] = {0, 0, 0};
       HIP_TRY(hipMemcpy(dbg, pp.qcounts.p + 100 + 4 * (b & 3), sizeof dbg, hipMemcpyDeviceToHost));

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
   };
 
   const unsigned long long t_start = a.wave_log ? wall_clock64() : 0ull;
-  uint32_t wave_iters = 0;
+  uint32_t wave_iters = 0, dbg_inner_lanes = 0, dbg_inner_steps = 0, dbg_leaf_lanes = 0, dbg_leaf_rounds = 0, dbg_busy_lanes = 0;
   for (;;) {
     if (FULLCTR) iters++;
     wave_iters++;
@@ -268,6 +268,12 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
 
     // ---- inner step for every lane standing on an inner node (P5/fsh:277-302)
     const bool at_inner = (int32_t)ref >= 0;
+    if (a.wave_log) {
+      const uint32_t ni = (uint32_t)__popcll(ballot(at_inner));
+      dbg_inner_lanes += ni;
+      dbg_inner_steps += ni ? 1u : 0u;
+      dbg_busy_lanes += (uint32_t)__popcll(ballot(ref != REF_NONE));
+    }
     if (at_inner) {
       if (FULLCTR) ctr.inner++;
       float4 q0, q1, q2, q3;
@@ -333,6 +339,10 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
           __builtin_amdgcn_wave_barrier();
           const int grp = lane >> (6 - sh), m = lane & (g - 1);
           const bool helper = grp < Lc;
+          if (a.wave_log) {
+            dbg_leaf_lanes += (uint32_t)Lc;
+            dbg_leaf_rounds++;
+          }
           const int src = helper ? wsrc[grp] : lane;
           const f3 cS = mk(__shfl(S.x, src, 64), __shfl(S.y, src, 64), __shfl(S.z, src, 64));
           const f3 cd = mk(__shfl(d.x, src, 64), __shfl(d.y, src, 64), __shfl(d.z, src, 64));
@@ -397,11 +407,13 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
   const unsigned long long rr = wave_sum(ctr.rays);
   if (lane == 0 && rr) atomicAdd(&a.counters[EZRT_CTR_RAYS], rr);
   if (a.wave_log && lane == 0) {
-    unsigned long long* w = a.wave_log + (size_t)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 4;
+    unsigned long long* w = a.wave_log + (size_t)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 8;
     w[0] = t_start;
     w[1] = wall_clock64();
-    w[2] = wave_iters;
-    w[3] = rr;
+    w[2] = wave_iters | ((unsigned long long)dbg_inner_steps << 32);
+    w[3] = rr | ((unsigned long long)dbg_inner_lanes << 32);
+    w[4] = dbg_leaf_lanes | ((unsigned long long)dbg_leaf_rounds << 32);
+    w[5] = dbg_busy_lanes;
   }
   if (FULLCTR) {
     const unsigned long long v1 = wave_sum(ctr.pops), v2 = wave_sum(ctr.inner), v3 = wave_sum(ctr.tris),
