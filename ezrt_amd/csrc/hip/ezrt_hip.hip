@@ -73,6 +73,8 @@ struct Tuning {
                            // end is paid twice: 3.81 vs 3.65 ms per C2 frame)
   int sub_frames = 0;      // frames per sub-chunk when pipelined (0: half the call's frames)
   int static_pct = 50;     // share of a trace queue dealt statically to the waves, percent (0: one pool each)
+  int refill_min = 16;     // free lanes a wave waits for before it runs its refill code (publish results, adopt the
+                           // prefetched ray, prefetch the next): wave-wide code for per-lane events, so batch it (+9 %)
   int steal = 1;           // intra-wave work stealing in traceq_kernel (+ a redo launch for exact ties)
   int debug_stages = 0;    // print per-stage queue sizes (synchronises)
 };
@@ -84,7 +86,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel}, {"packet", &T
                               {"packet_budget", &Tuning::packet_budget}, {"leaf_threshold", &Tuning::leaf_threshold},
                               {"pool_div", &Tuning::pool_div}, {"pool_max", &Tuning::pool_max},
                               {"trace_wps", &Tuning::trace_wps}, {"lds_nodes", &Tuning::lds_nodes},
-                              {"steal", &Tuning::steal}, {"static_pct", &Tuning::static_pct}, {"pipes", &Tuning::pipes}, {"sub_frames", &Tuning::sub_frames}, {"scatter", &Tuning::scatter}, {"debug_stages", &Tuning::debug_stages}};
+                              {"steal", &Tuning::steal}, {"refill_min", &Tuning::refill_min}, {"static_pct", &Tuning::static_pct}, {"pipes", &Tuning::pipes}, {"sub_frames", &Tuning::sub_frames}, {"scatter", &Tuning::scatter}, {"debug_stages", &Tuning::debug_stages}};
 Tuning tuning_from_env() {
   Tuning t;
   for (const TuningName& k : kTuning) {
@@ -412,6 +414,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     t.counters = s->counters.p;
     t.leaf_threshold = leaf_thr;
     t.static_pct = (uint32_t)(tu.static_pct < 0 ? 0 : (tu.static_pct > 95 ? 95 : tu.static_pct));
+    t.refill_min = (uint32_t)(tu.refill_min < 1 ? 1 : (tu.refill_min > 64 ? 64 : tu.refill_min));
     t.pool_div = (uint32_t)pool_div;
     t.pool_max = (uint32_t)pool_max;
     t.stack_entries = (int32_t)(lds / (BLOCK * sizeof(int)));

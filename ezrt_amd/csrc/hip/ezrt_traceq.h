@@ -21,6 +21,7 @@
 namespace ezd {
 
 constexpr uint32_t REF_NONE = 0xffffffffu; // a lane without a ray (every predicate below is ONE compare on `ref`)
+constexpr uint32_t REF_DONE = 0xfffffffeu; // traversal finished, {t, triangle} not stored yet (done in the batched refill)
 constexpr uint32_t TRACE_POOL_MIN = 8; // smallest reservation: short queues are spread over every wave
 
 struct RayQueue {
@@ -39,6 +40,7 @@ struct TraceQArgs {
   uint32_t* head;          // queue head (device, zeroed per launch)
   unsigned long long* counters;
   int32_t leaf_threshold;  // lanes waiting at a leaf that trigger the triangle phase
+  uint32_t refill_min;     // lanes that must be free before the wave runs its refill code
   uint32_t static_pct;     // share of the queue dealt statically (first pool of every wave), percent
   uint32_t pool_div, pool_max; // pool = clamp(n_rays / (n_waves * pool_div), 8, pool_max)
   int32_t lds_nodes;       // inner records [0, lds_nodes) staged in LDS (after stack + lane table)
@@ -112,8 +114,13 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
   uint32_t ray_p0 = 0, ray_t0 = 0, ray_i0 = 0, iters = 0;
   unsigned long long* hits64 = reinterpret_cast<unsigned long long*>(a.hits);
 
-  // end of this lane's (sub)traversal: publish {t, triangle}
+  // end of this lane's (sub)traversal; the result is stored by publish() when the wave next runs its refill code
   auto finish = [&]() {
+    ref = REF_DONE;
+    sp = 0;
+    sb = 0;
+  };
+  auto publish = [&]() {
     if (shared) { // several lanes contribute to this ray: merge with a 64-bit atomicMin
       if (best_tri >= 0) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(best_t) << 32) | (uint32_t)best_tri;
@@ -127,8 +134,6 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
     ref = REF_NONE;
     tie = false;
     shared = false;
-    sp = 0;
-    sb = 0;
     if (FULLCTR && a.dbg) {
       atomicMax(a.dbg, ctr.pops - ray_p0);
       atomicMax(a.dbg + 1, ctr.tris - ray_t0);
@@ -142,8 +147,11 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
     if (FULLCTR) iters++;
     wave_iters++;
     // ---- refill: lanes without work adopt their prefetched ray, then prefetch another
-    const bool want = ref == REF_NONE;
-    if (ballot(want)) {
+    const bool want = ref >= REF_DONE;
+    const unsigned long long wantm = ballot(want);
+    // (the refill code runs for the whole wave: batch it until a few lanes are free, or nobody has a ray)
+    if (wantm && ((uint32_t)__popcll(wantm) >= a.refill_min || !ballot(ref < REF_DONE))) {
+      if (ref == REF_DONE) publish();
       if (want && nx_slot != REF_NONE) {
         const uint32_t adopted = nx_slot;
         nx_slot = REF_NONE;
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
       const uint32_t ni = (uint32_t)__popcll(ballot(at_inner));
       dbg_inner_lanes += ni;
       dbg_inner_steps += ni ? 1u : 0u;
-      dbg_busy_lanes += (uint32_t)__popcll(ballot(ref != REF_NONE));
+      dbg_busy_lanes += (uint32_t)__popcll(ballot(ref < REF_DONE));
     }
     if (at_inner) {
       if (FULLCTR) ctr.inner++;
@@ -324,7 +332,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
     // ---- leaf phase (hitArray, P5/fsh:238-251): postponed until enough lanes wait at a leaf, or
     // nobody can step.  (Issuing the node and triangle fetches of one iteration together was tried:
     // +22 VGPRs cost a wave per SIMD and 10 % -- see DESIGN.md.)
-    const bool at_leaf = (int32_t)ref < -1; // bit 31 set, not REF_NONE
+    const bool at_leaf = (int32_t)ref < -2; // bit 31 set, not REF_NONE / REF_DONE
     const unsigned long long lm = ballot(at_leaf);
     if (lm) {
       const int Lc = (int)__popcll(lm);
