@@ -102,6 +102,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
   float4 nx_o = make_float4(0, 0, 0, 0), nx_d = make_float4(0, 0, 0, 0);
 
   bool wild = false; // ... needs the exact NaN-aware slab test
+  bool wave_wild = false; // wave-uniform: some lane may hold such a ray (refreshed whenever rays are adopted or stolen)
   uint32_t slot = 0;
   f3 S = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
   float best_t = INF;
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
           }
         }
       }
+      wave_wild = ballot(wild && ref < REF_DONE) != 0ull;
       const bool need = nx_slot == REF_NONE && !exhausted;
       const unsigned long long m = ballot(need);
       if (m) {
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
     if (!ballot((ref & nx_slot) != REF_NONE)) break; // no lane has a ray or a prefetched one
 
     // ---- work stealing: lanes with nothing left to fetch take the oldest pending subtree of a busy lane
-    if (a.steal) {
+    if (a.steal && exhausted) { // (while the queue still has rays, free lanes are about to be refilled)
       const bool idle = (ref & nx_slot) == REF_NONE;
       const unsigned long long im = ballot(idle);
       if (im) {
@@ -251,6 +253,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
           const float vsx = __shfl(S.x, src, 64), vsy = __shfl(S.y, src, 64), vsz = __shfl(S.z, src, 64);
           const float vdx = __shfl(d.x, src, 64), vdy = __shfl(d.y, src, 64), vdz = __shfl(d.z, src, 64);
           const int vwild = __shfl((int)wild, src, 64);
+          wave_wild = wave_wild || ballot(thief && vwild != 0) != 0ull; // (wave-uniform)
           if (thief) {
             shared = true;
             slot = vslot;
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
         q3 = r[3];
       }
       float d1, d2;
-      if (ballot(wild)) { // some lane's ray has a zero/NaN direction component: exact select form
+      if (wave_wild) { // some lane's ray has a zero/NaN direction component: exact select form
         d1 = hit_aabb(S, inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));
         d2 = hit_aabb(S, inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w));
       } else {
