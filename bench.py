@@ -183,7 +183,7 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-            "kernel": "ezd::traceq_kernel<false,5>",
+            "kernel": "ezd::traceq_kernel<false,6>",
             "alg_bytes_per_launch": int(bytes_trace // launches), "alg_bytes_per_ray": round(bytes_trace / c["rays"], 1),
             "launch_ms": round(ms_trace / launches, 4), "launches_per_step": launches,
             "counters_per_step": {k: c[k] for k in ("rays", "node_pops", "inner_pops", "tri_tests", "mat_fetch", "samples", "env_map", "env_cache")},

@@ -65,7 +65,8 @@ struct Tuning {
   int leaf_threshold = 24; // lanes waiting at a leaf that trigger the triangle phase
   int pool_div = 1;        // ray-index pool = clamp(n_rays / (n_waves * pool_div), 8, pool_max)
   int pool_max = 256;
-  int trace_wps = 5;       // traceq_kernel register budget: waves per SIMD (4, 5, 6 or 8)
+  int trace_wps = 6;       // traceq_kernel register budget: waves per SIMD (4, 5, 6 or 8); 6 = 80 VGPRs (8 B of
+                           // scratch) and fewer tree records in LDS, still +3.6 % over 5 since the loop got leaner
   int lds_nodes = 1 << 20; // cap on top-of-tree records staged in LDS
   int scatter = 1;         // primary rays enter the queue in a scattered 8x8 sub-block order (balances pools)
   int pipes = 1;           // 2: sub-chunks of a call alternate between two scratch sets on two streams (measured:
