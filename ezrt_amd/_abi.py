@@ -93,6 +93,8 @@ HOST_ABI = {
 BUILD_ABI = {
     "ezrt_build_lbvh": (C.c_int, [c_float_p, C.c_int, C.c_int, c_float_p, c_float_p, C.c_int, C.POINTER(C.c_int),
                                   c_float_p]),
+    "ezrt_build_sah": (C.c_int, [c_float_p, C.c_int, C.c_int, c_float_p, c_float_p, C.c_int, C.POINTER(C.c_int),
+                                 c_float_p]),
 }
 
 

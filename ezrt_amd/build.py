@@ -6,10 +6,20 @@ import numpy as np
 from . import _abi
 
 
+def build_sah(tri36, leaf_n=8):
+    """buildBVHwithSAH on the GPU: exactly the arrays of the host builder (HostScene.buildBVHwithSAH +
+    encode), for scenes where the host build dominates.  -> (triangles [n, 36], nodes [m, 12], device ms)."""
+    return _build("ezrt_build_sah", tri36, leaf_n)
+
+
 def build_lbvh(tri36, leaf_n=8):
     """tri36 [n, 36] (reference triangle layout) -> (triangles reordered [n, 36], nodes [m, 12] in the
     reference node layout, device build time in ms).  Runs on the GPU; raises when the HIP library or
     the GPU is missing (no CPU fallback)."""
+    return _build("ezrt_build_lbvh", tri36, leaf_n)
+
+
+def _build(entry, tri36, leaf_n):
     lib = _abi.load_hip()
     tri = np.ascontiguousarray(tri36, np.float32).reshape(-1, 36)
     n = tri.shape[0]
@@ -19,7 +29,7 @@ def build_lbvh(tri36, leaf_n=8):
     n_nodes = C.c_int(0)
     ms = C.c_float(0.0)
     fp = lambda a: a.ctypes.data_as(_abi.c_float_p)
-    rc = lib.ezrt_build_lbvh(fp(tri), n, int(leaf_n), fp(tri_out), fp(nodes), cap, C.byref(n_nodes), C.byref(ms))
+    rc = getattr(lib, entry)(fp(tri), n, int(leaf_n), fp(tri_out), fp(nodes), cap, C.byref(n_nodes), C.byref(ms))
     if rc != 0:
-        raise RuntimeError("ezrt_build_lbvh: %s" % lib.ezrt_last_error().decode())
+        raise RuntimeError("%s: %s" % (entry, lib.ezrt_last_error().decode()))
     return tri_out, np.ascontiguousarray(nodes[:n_nodes.value]), float(ms.value)

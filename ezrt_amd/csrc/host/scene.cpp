@@ -371,7 +371,9 @@ struct Builder {
       int s = order[(size_t)(l - l0 + i)];
       recs[(size_t)i] = SortRec{aux[(size_t)s].cen[axis], s};
     }
-    std::sort(recs.begin(), recs.end(), [](const SortRec& a, const SortRec& b) { return a.key < b.key; });
+    // std::sort leaves the order of equal keys to the library (parity unpinned); here equal
+    // keys keep their current order, which is what the numpy restatement and the GPU builder do too
+    std::stable_sort(recs.begin(), recs.end(), [](const SortRec& a, const SortRec& b) { return a.key < b.key; });
     for (int i = 0; i < n; i++) order[(size_t)(l - l0 + i)] = recs[(size_t)i].slot;
     stats.sorts++;
   }

@@ -24,6 +24,13 @@ extern "C" {
 int ezrt_build_lbvh(const float* tri, int n_tri, int leaf_n, float* tri_out, float* nodes_out, int nodes_capacity,
                     int* n_nodes, float* build_ms);
 
+/* buildBVHwithSAH itself on the GPU: same arguments as ezrt_build_lbvh, and EXACTLY the arrays the host
+ * sequence `nodes = {testNode}; buildBVHwithSAH(triangles, nodes, 0, n-1, leaf_n); encode` produces
+ * (ezrt::buildBVHwithSAH of include/ezrt_scene.hpp: same triangle order, same nodes, same ids) -- the
+ * parity builder, level by level with radix sorts and segmented scans instead of O(nodes) std::sort calls. */
+int ezrt_build_sah(const float* tri, int n_tri, int leaf_n, float* tri_out, float* nodes_out, int nodes_capacity,
+                   int* n_nodes, float* build_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -137,3 +137,69 @@ def test_lbvh_million_triangles(hip, oracle):
     s2 = c5.upload(oracle)
     t2, d2 = s2.query_hits(rays)
     assert np.array_equal(t2 >= 0, tg >= 0) and np.array_equal(_bits(d2), _bits(dg))
+
+
+# ---- buildBVHwithSAH on the GPU: the parity builder, bit-identical to the host builder
+def _host_build(tri36, leaf_n=8):
+    hs = S.HostScene()
+    hs.addTriangles(tri36)
+    hs.buildBVHwithSAH(leaf_n)
+    return hs.encode()
+
+
+def _random_tris(n, seed, ties=False):
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-2, 2, (n, 1, 3))
+    P = (c + rng.uniform(-0.3, 0.3, (n, 3, 3))).astype(np.float32)
+    if ties:  # snap to a coarse grid and repeat triangles: many equal centroid keys and equal costs
+        P = (np.round(P * 2) / 2).astype(np.float32)
+        P[n // 2:] = P[: n - n // 2]
+    T = np.zeros((n, 36), np.float32)
+    T[:, :9] = P.reshape(n, 9)
+    T[:, 9:18] = np.tile([0, 1, 0], 3)
+    T[:, 18:21] = np.arange(n, dtype=np.float32)[:, None]   # tell repeated triangles apart
+    return T
+
+
+@pytest.mark.parametrize("n,seed,ties,leaf", [(1, 1, False, 8), (9, 2, False, 8), (300, 3, False, 8), (5000, 4, False, 4),
+                                              (4000, 5, True, 8), (777, 6, True, 1)])
+def test_gpu_sah_builder_equals_the_host_builder(hip, n, seed, ties, leaf):
+    T = _random_tris(n, seed, ties)
+    tri_h, nodes_h = _host_build(T, leaf)
+    tri_g, nodes_g, ms = build.build_sah(T, leaf)
+    assert np.array_equal(_bits(tri_g), _bits(tri_h))
+    assert nodes_g.shape == nodes_h.shape and np.array_equal(_bits(nodes_g), _bits(nodes_h))
+
+
+def test_gpu_sah_builder_on_the_bench_scene_and_the_inf_cap(hip, bunny_small):
+    # C2's tree (79 820 triangles): bunny_scene(subdiv=2) went through the host builder
+    c2 = scenes.bunny_scene(subdiv=2)
+    hs_tri = c2.tri
+    # feed the GPU builder the same INPUT order the host builder saw: rebuild the un-sorted triangle list
+    hs = S.HostScene()
+    bv, bf = scenes.subdivide(*scenes.mesh("bunny"), 2)
+    hs.readObjText(scenes.obj_text(bv, bf), S.Material.disney(baseColor=(1, 1, 1)),
+                   S.getTransformMatrix((0, 0, 0), (0.3, -1.6, 0), (1.5, 1.5, 1.5)), True)
+    qv, qf = scenes.mesh("quad")
+    hs.readObjText(scenes.obj_text(qv, qf), S.Material.disney(baseColor=(0.725, 0.71, 0.68)),
+                   S.getTransformMatrix((0, 0, 0), (0, -1.4, 0), (18.83, 0.01, 18.83)), False)
+    sv, sf = scenes.mesh("sphere")
+    hs.readObjText(scenes.obj_text(sv, sf), S.Material.disney(baseColor=(1, 1, 1), emissive=(30, 20, 10)),
+                   S.getTransformMatrix((0, 0, 0), (0.0, 0.9, -0.0), (1, 1, 1)), False)
+    raw, _ = hs.encode()
+    tri_g, nodes_g, ms = build.build_sah(raw, 8)
+    print("GPU buildBVHwithSAH of %d triangles: %.1f ms on the device" % (raw.shape[0], ms))
+    assert np.array_equal(_bits(tri_g), _bits(hs_tri)) and np.array_equal(_bits(nodes_g), _bits(c2.nodes))
+    assert c2.build_stats["inf_cap_nodes"] > 0     # the INF = 114514 fallback is part of this tree
+
+
+def test_gpu_sah_builder_million_triangles(hip):
+    import time
+    t0 = time.time()
+    a = scenes.mega_scene(gpu_build=False)
+    t1 = time.time()
+    b = scenes.mega_scene(gpu_build=True)
+    t2 = time.time()
+    print("C5 scene: host build path %.1f s, GPU build path %.1f s (device part %.0f ms)" %
+          (t1 - t0, t2 - t1, b.build_stats["gpu_build_ms"]))
+    assert np.array_equal(_bits(a.tri), _bits(b.tri)) and np.array_equal(_bits(a.nodes), _bits(b.nodes))
