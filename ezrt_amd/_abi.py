@@ -95,6 +95,8 @@ BUILD_ABI = {
                                   c_float_p]),
     "ezrt_build_sah": (C.c_int, [c_float_p, C.c_int, C.c_int, c_float_p, c_float_p, C.c_int, C.POINTER(C.c_int),
                                  c_float_p]),
+    "ezrt_build_median": (C.c_int, [c_float_p, C.c_int, C.c_int, c_float_p, c_float_p, C.c_int, C.POINTER(C.c_int),
+                                    c_float_p]),
 }
 
 

@@ -12,6 +12,11 @@ def build_sah(tri36, leaf_n=8):
     return _build("ezrt_build_sah", tri36, leaf_n)
 
 
+def build_median(tri36, leaf_n=8):
+    """buildBVH (median split) on the GPU: exactly the arrays of HostScene.buildBVH + encode."""
+    return _build("ezrt_build_median", tri36, leaf_n)
+
+
 def build_lbvh(tri36, leaf_n=8):
     """tri36 [n, 36] (reference triangle layout) -> (triangles reordered [n, 36], nodes [m, 12] in the
     reference node layout, device build time in ms).  Runs on the GPU; raises when the HIP library or

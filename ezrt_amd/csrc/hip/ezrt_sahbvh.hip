@@ -218,8 +218,10 @@ struct HostNode { // the reference's BVHNode + what the numbering pass needs
 
 } // namespace
 
-extern "C" int ezrt_build_sah(const float* tri, int n_tri, int leaf_n, float* tri_out, float* nodes_out,
-                              int nodes_capacity, int* n_nodes, float* build_ms) {
+namespace {
+// median = false: buildBVHwithSAH (P3/main.cpp:457-588); true: buildBVH (P3/main.cpp:394-454)
+int build_level_sync(bool median, const float* tri, int n_tri, int leaf_n, float* tri_out, float* nodes_out,
+                     int nodes_capacity, int* n_nodes, float* build_ms) {
   if (!tri || !tri_out || !nodes_out || !n_nodes) return ezrt_fail_msg(EZRT_ERR_INVALID, "NULL argument");
   if (n_tri <= 0) return ezrt_fail_msg(EZRT_ERR_INVALID, "no triangles");
   if (n_tri >= (1 << 24)) return ezrt_fail_msg(EZRT_ERR_UNSUPPORTED, "counts >= 2^24 are not exact in the float encoding");
@@ -352,6 +354,40 @@ extern "C" int ezrt_build_sah(const float* tri, int n_tri, int leaf_n, float* tr
     SB_TRY(hipMemcpyAsync(d_split_ids.p, split_ids.data(), (size_t)n_split * sizeof(int), hipMemcpyHostToDevice, nullptr));
     SB_TRY(hipMemcpyAsync(d_off_b.p, off_b.data(), (size_t)n_split * sizeof(int), hipMemcpyHostToDevice, nullptr));
     SB_TRY(hipMemcpyAsync(d_off_e.p, off_e.data(), (size_t)n_split * sizeof(int), hipMemcpyHostToDevice, nullptr));
+    best.resize((size_t)n_split);
+    if (median) {
+      // buildBVH: sort along EVERY axis whose extent is >= the other two (three independent ifs: on ties the
+      // last matching axis has the last word), split in the middle
+      std::vector<Seg> pass(segs);
+      for (int axis = 0; axis < 3; axis++) {
+        bool any = false;
+        for (int k = 0; k < n_segs; k++) {
+          pass[(size_t)k].split = 0;
+          if (!segs[(size_t)k].split) continue;
+          const HostNode& h = nodes[(size_t)frontier_node[(size_t)k]];
+          const float len[3] = {h.BB[0] - h.AA[0], h.BB[1] - h.AA[1], h.BB[2] - h.AA[2]};
+          const int b = (axis + 1) % 3, c = (axis + 2) % 3;
+          if (len[axis] >= len[b] && len[axis] >= len[c]) {
+            pass[(size_t)k].split = 1;
+            any = true;
+          }
+        }
+        if (!any) continue;
+        SB_TRY(hipMemcpy(d_segs.p, pass.data(), (size_t)n_segs * sizeof(Seg), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_keys, dim3(grid_n), dim3(TPB), 0, nullptr, d_segs.p, d_seg_of.p, d_order[cur].p, d_aux.p, n, axis,
+                           d_keys[0].p);
+        need = tmp_bytes;
+        SB_TRY(rocprim::radix_sort_pairs(d_tmp.p, need, d_keys[0].p, d_keys[1].p, d_order[cur].p, d_order[cur ^ 1].p, (size_t)n,
+                                         0, 56, nullptr));
+        cur ^= 1;
+      }
+      for (int k = 0; k < n_split; k++) {
+        const Seg& sg = segs[(size_t)split_ids[(size_t)k]];
+        best[(size_t)k].cost = 0.0f;
+        best[(size_t)k].axis = 0;
+        best[(size_t)k].split = (sg.l + sg.r) / 2;
+      }
+    } else {
     for (int axis = 0; axis < 4; axis++) { // 0..2: the three sweeps; 3: the final sort on each range's best axis
       hipLaunchKernelGGL(k_keys, dim3(grid_n), dim3(TPB), 0, nullptr, d_segs.p, d_seg_of.p, d_order[cur].p, d_aux.p, n,
                          axis < 3 ? axis : -1, d_keys[0].p);
@@ -378,8 +414,8 @@ extern "C" int ezrt_build_sah(const float* tri, int n_tri, int leaf_n, float* tr
         hipLaunchKernelGGL(k_set_axis, dim3((n_split + TPB - 1) / TPB), dim3(TPB), 0, nullptr, d_split_ids.p, d_best.p, n_split,
                            d_segs.p);
     }
-    best.resize((size_t)n_split);
     SB_TRY(hipMemcpy(best.data(), d_best.p, (size_t)n_split * sizeof(Best), hipMemcpyDeviceToHost));
+    }
     // children, in range order
     std::vector<int> next;
     next.reserve((size_t)n_segs + (size_t)n_split);
@@ -458,4 +494,14 @@ extern "C" int ezrt_build_sah(const float* tri, int n_tri, int leaf_n, float* tr
   *n_nodes = total;
   if (build_ms) *build_ms = ms;
   return 0;
+}
+} // namespace
+
+extern "C" int ezrt_build_sah(const float* tri, int n_tri, int leaf_n, float* tri_out, float* nodes_out,
+                              int nodes_capacity, int* n_nodes, float* build_ms) {
+  return build_level_sync(false, tri, n_tri, leaf_n, tri_out, nodes_out, nodes_capacity, n_nodes, build_ms);
+}
+extern "C" int ezrt_build_median(const float* tri, int n_tri, int leaf_n, float* tri_out, float* nodes_out,
+                                 int nodes_capacity, int* n_nodes, float* build_ms) {
+  return build_level_sync(true, tri, n_tri, leaf_n, tri_out, nodes_out, nodes_capacity, n_nodes, build_ms);
 }

@@ -30,6 +30,10 @@ int ezrt_build_lbvh(const float* tri, int n_tri, int leaf_n, float* tri_out, flo
  * parity builder, level by level with radix sorts and segmented scans instead of O(nodes) std::sort calls. */
 int ezrt_build_sah(const float* tri, int n_tri, int leaf_n, float* tri_out, float* nodes_out, int nodes_capacity,
                    int* n_nodes, float* build_ms);
+/* buildBVH (the median-split builder, P3/main.cpp:394-454) on the GPU, same contract: exactly the arrays of
+ * `nodes = {testNode}; buildBVH(triangles, nodes, 0, n-1, leaf_n); encode`. */
+int ezrt_build_median(const float* tri, int n_tri, int leaf_n, float* tri_out, float* nodes_out, int nodes_capacity,
+                      int* n_nodes, float* build_ms);
 
 #ifdef __cplusplus
 }

@@ -203,3 +203,15 @@ def test_gpu_sah_builder_million_triangles(hip):
     print("C5 scene: host build path %.1f s, GPU build path %.1f s (device part %.0f ms)" %
           (t1 - t0, t2 - t1, b.build_stats["gpu_build_ms"]))
     assert np.array_equal(_bits(a.tri), _bits(b.tri)) and np.array_equal(_bits(a.nodes), _bits(b.nodes))
+
+
+@pytest.mark.parametrize("n,seed,ties,leaf", [(1, 1, False, 8), (300, 3, False, 8), (5000, 4, False, 4), (4000, 5, True, 8)])
+def test_gpu_median_builder_equals_the_host_builder(hip, n, seed, ties, leaf):
+    T = _random_tris(n, seed, ties)
+    hs = S.HostScene()
+    hs.addTriangles(T)
+    hs.buildBVH(leaf)
+    tri_h, nodes_h = hs.encode()
+    tri_g, nodes_g, _ = build.build_median(T, leaf)
+    assert np.array_equal(_bits(tri_g), _bits(tri_h))
+    assert nodes_g.shape == nodes_h.shape and np.array_equal(_bits(nodes_g), _bits(nodes_h))
