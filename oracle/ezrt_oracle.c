@@ -887,9 +887,13 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum, vo
     cx.ctr = &local;
     cx.full = s->instr > 0;
     cx.p5tri = (p->integrator >= 50);
+    /* tasks = 32-pixel pieces of a row, handed out dynamically: a 512-row image on a 256-core host would
+     * otherwise give every thread two whole rows of very different cost */
+    const int nxt = (p->x1 - p->x0 + 31) / 32, n_tasks = (p->y1 - p->y0) * (nxt > 0 ? nxt : 0);
 #pragma omp for schedule(dynamic, 1)
-    for (int y = p->y0; y < p->y1; y++) {
-      for (int x = p->x0; x < p->x1; x++) {
+    for (int task = 0; task < n_tasks; task++) {
+      const int y = p->y0 + task / nxt, xs = p->x0 + (task % nxt) * 32, xe = xs + 32 < p->x1 ? xs + 32 : p->x1;
+      for (int x = xs; x < xe; x++) {
         if (!pixel_owned(p, x, y)) continue;
         float* px = accum + ((size_t)y * p->width + x) * 4;
         v3 mean = V3(px[0], px[1], px[2]);
