@@ -201,6 +201,16 @@ def main():
             ora = trace.TraceLib(_abi.declare_trace_abi(ctypes.CDLL(opath)))
             so = bs.upload(ora)
             cores = os.cpu_count() or 1
+            try:  # a container's CPU quota (cgroup v2) is what the oracle really gets
+                quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+                if quota != "max":
+                    cores = max(1, min(cores, int(int(quota) / int(period))))
+            except (OSError, ValueError):
+                pass
+            try:
+                ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+            except OSError:
+                pass
             img = np.zeros((H, W, 4), np.float32)
             t1 = time.perf_counter()
             so.render(trace.make_params(W, H, eye, cam, args.integrator, args.bounces, spp=1), img)
@@ -225,7 +235,7 @@ def main():
                     n_total += extra
             cr = so.counters()["rays"]
             out["cpu_baseline"] = {"value": round(cr / d_total / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-                                   "sample": "frames 1..%d of the same %dx%d workload (%d rays, %.1f s), OpenMP over rows"
+                                   "sample": "frames 1..%d of the same %dx%d workload (%d rays, %.1f s), OpenMP over 32-pixel row pieces"
                                              % (n_total, W, H, cr, d_total)}
             if linf is not None:
                 out["cpu_baseline"]["linf_vs_gpu"] = linf
