@@ -6,7 +6,11 @@
 //
 //  * persistent workgroups; each lane owns one ray at a time and keeps its NEXT ray prefetched in
 //    registers, so a lane that finishes refills without a memory round trip and a wave never
-//    idles behind its slowest ray.  Waves reserve queue indices in pools (one atomic per pool);
+//    idles behind its slowest ray.  Waves own interleaved static pools of queue indices and
+//    reserve the rest dynamically (one atomic per pool of 256);
+//  * per-lane events are batched: storing a finished ray's result, adopting the prefetched ray and
+//    prefetching the next one is wave-wide code, so it only runs once `refill_min` lanes are free;
+//  * lane state lives in `ref` (node / leaf / REF_DONE / REF_NONE): every predicate is one compare;
 //  * the breadth-first top of the tree is staged in LDS once per workgroup (80-B stride, explicit
 //    LDS address space so the compiler emits ds_read_b128, not flat loads);
 //  * per-lane traversal stack in LDS, stack[row][256]: bank = lane % 32, conflict-free;
@@ -37,11 +41,11 @@ struct TraceQArgs {
   uint32_t rays_per_path;
   uint32_t const_origin;   // 1: every ray of this queue starts at `origin` (primary rays); rq.o is not read
   float origin[3];
-  uint32_t* head;          // queue head (device, zeroed per launch)
+  uint32_t* head;          // head of the dynamically reserved part of the queue (device, zeroed per launch)
   unsigned long long* counters;
   int32_t leaf_threshold;  // lanes waiting at a leaf that trigger the triangle phase
   uint32_t refill_min;     // lanes that must be free before the wave runs its refill code
-  uint32_t static_pct;     // share of the queue dealt statically (first pool of every wave), percent
+  uint32_t static_pct;     // share of the queue dealt statically (interleaved rounds of pools), percent
   uint32_t pool_div, pool_max; // pool = clamp(n_rays / (n_waves * pool_div), 8, pool_max)
   int32_t lds_nodes;       // inner records [0, lds_nodes) staged in LDS (after stack + lane table)
   int32_t stack_entries;   // LDS stack rows (tree depth); the per-wave lane table follows them
@@ -59,7 +63,8 @@ struct TraceQArgs {
   uint32_t* redo_count;
   uint32_t* redo_slots;
   uint32_t* redo_flag; // one word per ray slot: a ray is appended once (cleared again by the redo launch)
-  unsigned long long* wave_log; // diagnostic (debug_stages=2): per wave {start, end (100 MHz ticks), iterations, rays}
+  unsigned long long* wave_log; // diagnostic (debug_stages=2): per wave 8 words {start, end (100 MHz ticks), iterations |
+                                // inner steps, rays | inner lanes, leaf rays | leaf rounds, busy lanes, -, -}
 };
 
 EZD uint32_t lane_rank(unsigned long long mask) { // number of set bits below this lane
