@@ -373,7 +373,8 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
   }
   HIP_TRY(pp.sobol_tab.ensure((size_t)nf * 8));
   a.sobol_tab = pp.sobol_tab.p;
-  hipLaunchKernelGGL(sobol_kernel, dim3((unsigned)((nf * 8 + 255) / 256)), dim3(256), 0, st, frame_first + 1u, (int)nf, 8, pp.sobol_tab.p);
+  a.sobol_out = pp.sobol_tab.p;
+  a.n_frames = nf;
   hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((n_slots + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, a);
 
   const size_t lds = stack_lds_bytes(s);

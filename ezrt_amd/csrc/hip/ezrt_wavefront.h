@@ -49,7 +49,9 @@ struct WfArgs {
   const uint32_t* n_in;    // paths in the input queue (device)
   uint32_t* n_out;         // paths in the output queue (device, atomically grown)
   int32_t bounce;          // the bounce this stage starts (0 = consumes the primary hits)
-  const float* sobol_tab;  // [frame - frame_first][8]: sobol(d, grayCode(frame + 1)), filled once per chunk
+  const float* sobol_tab;  // [frame - frame_first][8]: sobol(d, grayCode(frame + 1)), filled by raygen_kernel
+  float* sobol_out;        // (the same table, as raygen_kernel writes it)
+  uint32_t n_frames;       // frames of the chunk
   uint32_t scatter;        // queue order of the primary rays: see queue_to_sample (1 = identity)
   uint32_t scatter_shift;  // scattered granule = 1 << scatter_shift slots (6: 8x8 sub-block, 8: 16x16 block, 5: 8x4 pixels)
 };
@@ -86,6 +88,9 @@ __global__ __launch_bounds__(BLOCK) void raygen_kernel(WfArgs a) {
   const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
   if (slot >= a.n_slots) return;
   if (slot == 0) *a.n_out = a.n_slots; // stage 0's path count, read by the first trace launch
+  if (blockIdx.x == 0) // the chunk's Sobol table (read by the shading stages): sobol(d, grayCode(frame + 1)), 8 dims per frame
+    for (uint32_t k = threadIdx.x; k < a.n_frames * 8u; k += BLOCK)
+      a.sobol_out[k] = sobol(k & 7u, gray_code(a.frame_first + (k >> 3) + 1u));
   int x, y;
   uint32_t frame;
   slot_to_pixel(a.blocks, a.n_blocks, queue_to_sample(slot, (uint32_t)a.n_blocks, a.scatter, a.scatter_shift), a.frame_first, x, y, frame);
