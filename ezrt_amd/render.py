@@ -24,7 +24,6 @@ import os
 import sys
 import time
 
-import numpy as np
 
 from . import build, imageio, progressive, scenes, trace
 from . import scene as S

@@ -6,7 +6,7 @@ buildBVHwithSAH, encode loops, HDRLoader.load, calculateHdrCache
 (P3/main.cpp:28-57, 254-588, 720-748; P5/main.cpp:592-689).
 """
 import ctypes as C
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 
 import numpy as np
 
