@@ -76,6 +76,7 @@ struct Tuning {
   int static_pct = 50;     // share of a trace queue dealt statically to the waves, percent (0: one pool each)
   int refill_min = 16;     // free lanes a wave waits for before it runs its refill code (publish results, adopt the
                            // prefetched ray, prefetch the next): wave-wide code for per-lane events, so batch it (+9 %)
+  int split_shade = 1;     // bounce >= 1: leaving paths and surface interactions shaded by two kernels
   int steal = 1;           // intra-wave work stealing in traceq_kernel (+ a redo launch for exact ties)
   int debug_stages = 0;    // print per-stage queue sizes (synchronises)
 };
@@ -87,7 +88,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel}, {"packet", &T
                               {"packet_budget", &Tuning::packet_budget}, {"leaf_threshold", &Tuning::leaf_threshold},
                               {"pool_div", &Tuning::pool_div}, {"pool_max", &Tuning::pool_max},
                               {"trace_wps", &Tuning::trace_wps}, {"lds_nodes", &Tuning::lds_nodes},
-                              {"steal", &Tuning::steal}, {"refill_min", &Tuning::refill_min}, {"static_pct", &Tuning::static_pct}, {"pipes", &Tuning::pipes}, {"sub_frames", &Tuning::sub_frames}, {"scatter", &Tuning::scatter}, {"debug_stages", &Tuning::debug_stages}};
+                              {"steal", &Tuning::steal}, {"split_shade", &Tuning::split_shade}, {"refill_min", &Tuning::refill_min}, {"static_pct", &Tuning::static_pct}, {"pipes", &Tuning::pipes}, {"sub_frames", &Tuning::sub_frames}, {"scatter", &Tuning::scatter}, {"debug_stages", &Tuning::debug_stages}};
 Tuning tuning_from_env() {
   Tuning t;
   for (const TuningName& k : kTuning) {
@@ -113,6 +114,7 @@ struct Pipe {
   DevBuf<uint32_t> qcounts; // [0..63] path counts per stage, [64..99] trace queue heads, [100..115] debug,
                             // [120] redo count, [121] redo queue head
   DevBuf<uint32_t> redo_slots;
+  DevBuf<uint32_t> defer_list;  // split shading: paths with a surface interaction
   hipStream_t stream = nullptr;  // own stream (pipelined calls only)
   hipEvent_t ev_done = nullptr;  // samples of the sub-chunk are complete
   hipEvent_t ev_free = nullptr;  // ... and have been folded into the frame buffer
@@ -281,6 +283,24 @@ void launch_shade_i(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
   if (full) hipLaunchKernelGGL((shade_kernel<INTEG, true>), grid, dim3(SHADE_BLOCK), 0, st, a);
   else hipLaunchKernelGGL((shade_kernel<INTEG, false>), grid, dim3(SHADE_BLOCK), 0, st, a);
 }
+template <int INTEG>
+void launch_shade_split_i(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st) {
+  if (full) {
+    hipLaunchKernelGGL((shade_miss_kernel<INTEG, true>), grid, dim3(SHADE_BLOCK), 0, st, a);
+    hipLaunchKernelGGL((shade_hit_kernel<INTEG, true>), grid_hit, dim3(SHADE_BLOCK), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((shade_miss_kernel<INTEG, false>), grid, dim3(SHADE_BLOCK), 0, st, a);
+    hipLaunchKernelGGL((shade_hit_kernel<INTEG, false>), grid_hit, dim3(SHADE_BLOCK), 0, st, a);
+  }
+}
+void launch_shade_split(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st) {
+  switch (a.p.integrator) {
+    case EZRT_INTEGRATOR_P3_DIFFUSE: launch_shade_split_i<EZRT_INTEGRATOR_P3_DIFFUSE>(a, full, grid, grid_hit, st); break;
+    case EZRT_INTEGRATOR_P4_DISNEY: launch_shade_split_i<EZRT_INTEGRATOR_P4_DISNEY>(a, full, grid, grid_hit, st); break;
+    case EZRT_INTEGRATOR_P5_SOBOL: launch_shade_split_i<EZRT_INTEGRATOR_P5_SOBOL>(a, full, grid, grid_hit, st); break;
+    default: launch_shade_split_i<EZRT_INTEGRATOR_P5_MIS>(a, full, grid, grid_hit, st); break;
+  }
+}
 void launch_shade(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
   switch (a.p.integrator) {
     case EZRT_INTEGRATOR_P3_DIFFUSE: launch_shade_i<EZRT_INTEGRATOR_P3_DIFFUSE>(a, full, grid, st); break;
@@ -310,8 +330,9 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
   }
   // [0..63] paths per stage, [64..99] queue heads, [100..119] debug, [120,121] packet redo,
   // [128..] redo counts per stage, [192..] redo queue heads per stage
-  HIP_TRY(pp.qcounts.ensure(256));
-  HIP_TRY(hipMemsetAsync(pp.qcounts.p, 0, 256 * sizeof(uint32_t), st));
+  HIP_TRY(pp.qcounts.ensure(320));
+  HIP_TRY(hipMemsetAsync(pp.qcounts.p, 0, 320 * sizeof(uint32_t), st));
+  HIP_TRY(pp.defer_list.ensure(n_slots));
   if (!s->num_cus) {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -504,7 +525,10 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     a.n_in = pp.qcounts.p + b;
     a.n_out = pp.qcounts.p + b + 1;
     a.bounce = b;
-    launch_shade(a, full, dim3(shade_grid), st);
+    a.n_defer = pp.qcounts.p + 256 + b;
+    a.defer_list = pp.defer_list.p;
+    if (b >= 1 && tu.split_shade) launch_shade_split(a, full, dim3(shade_grid), dim3(shade_grid / 4 ? shade_grid / 4 : 1), st);
+    else launch_shade(a, full, dim3(shade_grid), st);
     if (debug_stages) { // diagnostic only: per-stage queue sizes and counters (synchronises)
       uint32_t q[2] = {0, 0};
       unsigned long long c[EZRT_CTR_COUNT];

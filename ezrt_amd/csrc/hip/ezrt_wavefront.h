@@ -52,6 +52,8 @@ struct WfArgs {
   const float* sobol_tab;  // [frame - frame_first][8]: sobol(d, grayCode(frame + 1)), filled by raygen_kernel
   float* sobol_out;        // (the same table, as raygen_kernel writes it)
   uint32_t n_frames;       // frames of the chunk
+  uint32_t* n_defer;       // split shading (bounce >= 1): paths with a surface interaction, listed by shade_miss_kernel
+  uint32_t* defer_list;    // ... and shaded by shade_hit_kernel
   uint32_t scatter;        // queue order of the primary rays: see queue_to_sample (1 = identity)
   uint32_t scatter_shift;  // scattered granule = 1 << scatter_shift slots (6: 8x8 sub-block, 8: 16x16 block, 5: 8x4 pixels)
 };
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(BLOCK) void raygen_kernel(WfArgs a) {
 
 // ---------------------------------------------------------------------------
 // shading stage
+constexpr int SHADE_MISS_WAVES = 8; // waves/SIMD the miss half of the split shading is compiled for (<= 64 VGPRs)
 constexpr int SHADE_BLOCK = 512; // 8 waves share ONE queue-tail atomic per iteration (see block_alloc); two workgroups
                                  // per CU, so one computes while the other sits in its barriers (1024: -3 %, 256: atomic-bound)
 
@@ -405,6 +408,59 @@ EZD void shade_emit(const WfArgs& a, const ShadeOut& o, uint32_t* alloc_lds) {
   } else {
     a.rq_out.o[k] = make_float4(o.P.x, o.P.y, o.P.z, 0.0f);
     a.rq_out.d[k] = make_float4(o.rayL.x, o.rayL.y, o.rayL.z, 1.0f);
+  }
+}
+
+// Split shading of bounce >= 1 (split_shade): bounce rays mostly leave the scene, and everything a leaving
+// path needs (state loads, environment lookup, sample store) fits in a few dozen registers -- so that part
+// runs as its own kernel at twice the occupancy of the full shading kernel and lists the paths with a
+// surface interaction, which a second kernel then shades in dense waves.
+template <int INTEG, bool FULLCTR>
+__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MISS_WAVES) void shade_miss_kernel(WfArgs a) {
+  __shared__ uint32_t alloc_lds[SHADE_BLOCK / 64 + 1];
+  const uint32_t n_in = *a.n_in;
+  const uint32_t stride = gridDim.x * SHADE_BLOCK;
+  const uint32_t n_round = (n_in + stride - 1) / stride * stride;
+  Counters ctr = {0, 0, 0, 0, 0, 0, 0};
+  uint32_t n_samples = 0;
+  for (uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x; i < n_round; i += stride) {
+    ShadeOut o;
+    const bool deferred = shade_path<INTEG, FULLCTR, 1>(a, i, i < n_in, ctr, n_samples, o);
+    const uint32_t k = block_alloc(a.n_defer, deferred, alloc_lds);
+    if (deferred) a.defer_list[k] = i;
+  }
+  if (FULLCTR) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long v5 = wave_sum(ctr.envmap), v6 = wave_sum(ctr.envcache);
+    if (lane == 0) {
+      atomicAdd(&a.counters[EZRT_CTR_ENV_MAP], v5);
+      atomicAdd(&a.counters[EZRT_CTR_ENV_CACHE], v6);
+    }
+  }
+}
+
+template <int INTEG, bool FULLCTR>
+__global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_hit_kernel(WfArgs a) {
+  __shared__ uint32_t alloc_lds[SHADE_BLOCK / 64 + 1];
+  constexpr bool MIS = (INTEG == EZRT_INTEGRATOR_P5_MIS);
+  const uint32_t n_in = *a.n_defer;
+  const uint32_t stride = gridDim.x * SHADE_BLOCK;
+  const uint32_t n_round = (n_in + stride - 1) / stride * stride;
+  Counters ctr = {0, 0, 0, 0, 0, 0, 0};
+  uint32_t n_samples = 0;
+  for (uint32_t j = blockIdx.x * SHADE_BLOCK + threadIdx.x; j < n_round; j += stride) {
+    ShadeOut o;
+    o.emit = false;
+    if (j < n_in) shade_path<INTEG, FULLCTR, 2>(a, a.defer_list[j], true, ctr, n_samples, o);
+    shade_emit<MIS>(a, o, alloc_lds);
+  }
+  if (FULLCTR) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long v5 = wave_sum(ctr.envmap), v6 = wave_sum(ctr.envcache);
+    if (lane == 0) {
+      atomicAdd(&a.counters[EZRT_CTR_ENV_MAP], v5);
+      atomicAdd(&a.counters[EZRT_CTR_ENV_CACHE], v6);
+    }
   }
 }
 
