@@ -78,6 +78,14 @@ struct Counters { // per-thread, registers
 
 // ---------------------------------------------------------------------------
 // RNG: P5/fsh:315-331
+// Work counters live in CTR_SLOTS copies (one 64-byte line each) and are summed by ezrt_counters: every wave adds
+// its totals when it retires, and ONE counter word only sustains ~88 atomics/us chip-wide -- the 32 768 waves of
+// the primary shading stage needed 370 us just to report their sample counts.
+constexpr int CTR_SLOTS = 64;
+EZD unsigned long long* ctr_slot(unsigned long long* base) {
+  return base + (size_t)((blockIdx.x * 5u + (threadIdx.x >> 6)) & (CTR_SLOTS - 1)) * EZRT_CTR_COUNT;
+}
+
 // Lane mask of a predicate.  (HIP's __ballot takes an int: the bool is first materialised as 0/1
 // in a VGPR and compared again -- two VALU slots per test in a VALU-bound loop.)
 EZD unsigned long long ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }

@@ -76,7 +76,7 @@ struct Tuning {
   int static_pct = 50;     // share of a trace queue dealt statically to the waves, percent (0: one pool each)
   int refill_min = 16;     // free lanes a wave waits for before it runs its refill code (publish results, adopt the
                            // prefetched ray, prefetch the next): wave-wide code for per-lane events, so batch it (+9 %)
-  int split_shade = 1;     // bounce >= 1: leaving paths and surface interactions shaded by two kernels
+  int split_shade = 2;     // leaving paths and surface interactions shaded by two kernels: 1 from bounce 1 on, 2 always
   int steal = 1;           // intra-wave work stealing in traceq_kernel (+ a redo launch for exact ties)
   int debug_stages = 0;    // print per-stage queue sizes (synchronises)
 };
@@ -114,7 +114,8 @@ struct Pipe {
   DevBuf<uint32_t> qcounts; // [0..63] path counts per stage, [64..99] trace queue heads, [100..115] debug,
                             // [120] redo count, [121] redo queue head
   DevBuf<uint32_t> redo_slots;
-  DevBuf<uint32_t> defer_list;  // split shading: paths with a surface interaction
+  DevBuf<uint32_t> defer_list;  // split shading: paths with a surface interaction, per workgroup
+  DevBuf<uint32_t> defer_count;
   hipStream_t stream = nullptr;  // own stream (pipelined calls only)
   hipEvent_t ev_done = nullptr;  // samples of the sub-chunk are complete
   hipEvent_t ev_free = nullptr;  // ... and have been folded into the frame buffer
@@ -283,15 +284,20 @@ void launch_shade_i(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
   if (full) hipLaunchKernelGGL((shade_kernel<INTEG, true>), grid, dim3(SHADE_BLOCK), 0, st, a);
   else hipLaunchKernelGGL((shade_kernel<INTEG, false>), grid, dim3(SHADE_BLOCK), 0, st, a);
 }
+template <int INTEG, bool B0>
+void launch_shade_split_ib(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st) {
+  if (full) {
+    hipLaunchKernelGGL((shade_miss_kernel<INTEG, true, B0>), grid, dim3(SHADE_BLOCK), 0, st, a);
+    hipLaunchKernelGGL((shade_hit_kernel<INTEG, true, B0>), grid_hit, dim3(SHADE_BLOCK), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((shade_miss_kernel<INTEG, false, B0>), grid, dim3(SHADE_BLOCK), 0, st, a);
+    hipLaunchKernelGGL((shade_hit_kernel<INTEG, false, B0>), grid_hit, dim3(SHADE_BLOCK), 0, st, a);
+  }
+}
 template <int INTEG>
 void launch_shade_split_i(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st) {
-  if (full) {
-    hipLaunchKernelGGL((shade_miss_kernel<INTEG, true>), grid, dim3(SHADE_BLOCK), 0, st, a);
-    hipLaunchKernelGGL((shade_hit_kernel<INTEG, true>), grid_hit, dim3(SHADE_BLOCK), 0, st, a);
-  } else {
-    hipLaunchKernelGGL((shade_miss_kernel<INTEG, false>), grid, dim3(SHADE_BLOCK), 0, st, a);
-    hipLaunchKernelGGL((shade_hit_kernel<INTEG, false>), grid_hit, dim3(SHADE_BLOCK), 0, st, a);
-  }
+  if (a.bounce == 0) launch_shade_split_ib<INTEG, true>(a, full, grid, grid_hit, st);
+  else launch_shade_split_ib<INTEG, false>(a, full, grid, grid_hit, st);
 }
 void launch_shade_split(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st) {
   switch (a.p.integrator) {
@@ -332,7 +338,8 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
   // [128..] redo counts per stage, [192..] redo queue heads per stage
   HIP_TRY(pp.qcounts.ensure(320));
   HIP_TRY(hipMemsetAsync(pp.qcounts.p, 0, 320 * sizeof(uint32_t), st));
-  HIP_TRY(pp.defer_list.ensure(n_slots));
+  HIP_TRY(pp.defer_list.ensure(n_slots + (size_t)2048 * 1024)); // per-workgroup regions: iterations x SHADE_BLOCK each
+  HIP_TRY(pp.defer_count.ensure(2048u * 1024u / SHADE_BLOCK));
   if (!s->num_cus) {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -376,7 +383,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
   a.bounce = 0;
   a.scatter = 1u;
   a.scatter_shift = 6u;
-  if (s->tune.scatter) { // multiplier near 0.618 * n_sub, coprime to n_sub
+  if (s->tune.scatter) { // multiplier coprime to n_sub
     a.scatter_shift = (uint32_t)(s->tune.scatter >= 4 && s->tune.scatter <= 8 ? s->tune.scatter : 6); // 1: 8x8 sub-blocks
     const uint32_t n_sub = ((uint32_t)nb * 256u) >> a.scatter_shift;
     auto gcd = [](uint32_t x, uint32_t y) {
@@ -387,9 +394,9 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
       }
       return x;
     };
-    uint32_t m = (uint32_t)((double)n_sub * 0.6180339887);
-    if (m < 1u) m = 1u;
-    while (gcd(m, n_sub) != 1u) m++;
+    uint32_t m = 2531u; // prime; consecutive queue granules land 2531 sub-blocks apart.  r * m must fit 32 bits:
+    if (n_sub > (1u << 20)) m = 1u; // (frames beyond 2^20 sub-blocks = 8k x 8k pixels keep the raster order)
+    while (m > 1u && gcd(m, n_sub) != 1u) m += 2u;
     a.scatter = m % n_sub ? m % n_sub : 1u;
   }
   HIP_TRY(pp.sobol_tab.ensure((size_t)nf * 8));
@@ -525,16 +532,24 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     a.n_in = pp.qcounts.p + b;
     a.n_out = pp.qcounts.p + b + 1;
     a.bounce = b;
-    a.n_defer = pp.qcounts.p + 256 + b;
     a.defer_list = pp.defer_list.p;
-    if (b >= 1 && tu.split_shade) launch_shade_split(a, full, dim3(shade_grid), dim3(shade_grid / 4 ? shade_grid / 4 : 1), st);
+    a.defer_count = pp.defer_count.p;
+    if ((b >= 1 && tu.split_shade) || tu.split_shade >= 2)
+      launch_shade_split(a, full, dim3(shade_grid), dim3(shade_grid), st);
     else launch_shade(a, full, dim3(shade_grid), st);
     if (debug_stages) { // diagnostic only: per-stage queue sizes and counters (synchronises)
       uint32_t q[2] = {0, 0};
       unsigned long long c[EZRT_CTR_COUNT];
       HIP_TRY(hipStreamSynchronize(st));
       HIP_TRY(hipMemcpy(q, pp.qcounts.p + b, sizeof q, hipMemcpyDeviceToHost));
-      HIP_TRY(hipMemcpy(c, s->counters.p, sizeof c, hipMemcpyDeviceToHost));
+      {
+        unsigned long long all[CTR_SLOTS * EZRT_CTR_COUNT];
+        HIP_TRY(hipMemcpy(all, s->counters.p, sizeof all, hipMemcpyDeviceToHost));
+        for (int k = 0; k < EZRT_CTR_COUNT; k++) {
+          c[k] = 0;
+          for (int j = 0; j < CTR_SLOTS; j++) c[k] += all[j * EZRT_CTR_COUNT + k];
+        }
+      }
       if (b == 0 && use_packet && !full) {
         uint32_t pk[3] = {0, 0, 0};
         HIP_TRY(hipMemcpy(pk, pp.qcounts.p + 116, sizeof pk, hipMemcpyDeviceToHost));
@@ -711,11 +726,11 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
   SC_TRY(s->tri_geom.ensure(geom.size()));
   SC_TRY(s->tri_ref.ensure((size_t)n_tri * EZRT_TRI_FLOATS));
   SC_TRY(s->inner.ensure(inner.size()));
-  SC_TRY(s->counters.ensure(EZRT_CTR_COUNT));
+  SC_TRY(s->counters.ensure((size_t)CTR_SLOTS * EZRT_CTR_COUNT));
   SC_TRY(hipMemcpy(s->tri_geom.p, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice));
   SC_TRY(hipMemcpy(s->tri_ref.p, tri, (size_t)n_tri * EZRT_TRI_FLOATS * sizeof(float), hipMemcpyHostToDevice));
   SC_TRY(hipMemcpy(s->inner.p, inner.data(), inner.size() * sizeof(float4), hipMemcpyHostToDevice));
-  SC_TRY(hipMemset(s->counters.p, 0, EZRT_CTR_COUNT * sizeof(unsigned long long)));
+  SC_TRY(hipMemset(s->counters.p, 0, (size_t)CTR_SLOTS * EZRT_CTR_COUNT * sizeof(unsigned long long)));
 #undef SC_TRY
   s->stats[0] = n_tri;
   s->stats[1] = n_nodes;
@@ -978,13 +993,18 @@ int ezrt_set_instrumentation(EzrtScene* s, int level) {
 int ezrt_counters(EzrtScene* s, uint64_t out[EZRT_CTR_COUNT]) {
   if (!s || !out) return fail(EZRT_ERR_INVALID, "NULL argument");
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out, s->counters.p, EZRT_CTR_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  unsigned long long all[CTR_SLOTS * EZRT_CTR_COUNT];
+  HIP_TRY(hipMemcpy(all, s->counters.p, sizeof all, hipMemcpyDeviceToHost));
+  for (int k = 0; k < EZRT_CTR_COUNT; k++) {
+    out[k] = 0;
+    for (int j = 0; j < CTR_SLOTS; j++) out[k] += all[j * EZRT_CTR_COUNT + k];
+  }
   return 0;
 }
 int ezrt_counters_reset(EzrtScene* s) {
   if (!s) return fail(EZRT_ERR_INVALID, "NULL argument");
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemset(s->counters.p, 0, EZRT_CTR_COUNT * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(s->counters.p, 0, (size_t)CTR_SLOTS * EZRT_CTR_COUNT * sizeof(unsigned long long)));
   return 0;
 }
 int ezrt_last_render_ms(EzrtScene* s, float* total_ms, float* trace_kernel_ms, int* n_trace_launches) {

@@ -225,19 +225,19 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
   // counters: one atomic per wave per slot
   unsigned long long r = wave_sum(ctr.rays), s = wave_sum(samples);
   if (lane == 0) {
-    atomicAdd(&a.counters[EZRT_CTR_RAYS], r);
-    atomicAdd(&a.counters[EZRT_CTR_SAMPLES], s);
+    atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_RAYS], r);
+    atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_SAMPLES], s);
   }
   if (FULLCTR) {
     unsigned long long v1 = wave_sum(ctr.pops), v2 = wave_sum(ctr.inner), v3 = wave_sum(ctr.tris),
                        v4 = wave_sum(ctr.mats), v5 = wave_sum(ctr.envmap), v6 = wave_sum(ctr.envcache);
     if (lane == 0) {
-      atomicAdd(&a.counters[EZRT_CTR_NODE_POPS], v1);
-      atomicAdd(&a.counters[EZRT_CTR_INNER_POPS], v2);
-      atomicAdd(&a.counters[EZRT_CTR_TRI_TESTS], v3);
-      atomicAdd(&a.counters[EZRT_CTR_MAT_FETCH], v4);
-      atomicAdd(&a.counters[EZRT_CTR_ENV_MAP], v5);
-      atomicAdd(&a.counters[EZRT_CTR_ENV_CACHE], v6);
+      atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_NODE_POPS], v1);
+      atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_INNER_POPS], v2);
+      atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_TRI_TESTS], v3);
+      atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_MAT_FETCH], v4);
+      atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_ENV_MAP], v5);
+      atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_ENV_CACHE], v6);
     }
   }
 }
@@ -320,14 +320,14 @@ __global__ __launch_bounds__(BLOCK) void query_kernel(QueryArgs a) {
     a.t[i] = (tri >= 0) ? t : INF;
   }
   unsigned long long rr = wave_sum(ctr.rays);
-  if ((threadIdx.x & 63) == 0) atomicAdd(&a.counters[EZRT_CTR_RAYS], rr);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_RAYS], rr);
   if (FULLCTR) {
     unsigned long long v1 = wave_sum(ctr.pops), v2 = wave_sum(ctr.inner), v3 = wave_sum(ctr.tris), v4 = wave_sum(ctr.mats);
     if ((threadIdx.x & 63) == 0) {
-      atomicAdd(&a.counters[EZRT_CTR_NODE_POPS], v1);
-      atomicAdd(&a.counters[EZRT_CTR_INNER_POPS], v2);
-      atomicAdd(&a.counters[EZRT_CTR_TRI_TESTS], v3);
-      atomicAdd(&a.counters[EZRT_CTR_MAT_FETCH], v4);
+      atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_NODE_POPS], v1);
+      atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_INNER_POPS], v2);
+      atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_TRI_TESTS], v3);
+      atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_MAT_FETCH], v4);
     }
   }
 }

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(BLOCK) void tracepk_kernel(TracePkArgs a) {
   }
   ndone_total += (unsigned long long)__popcll(ballot(valid && !redo));
   } // packets
-  if (lane == 0 && ndone_total) atomicAdd(&a.counters[EZRT_CTR_RAYS], ndone_total); // redone rays are counted by traceq
+  if (lane == 0 && ndone_total) atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_RAYS], ndone_total); // redone rays are counted by traceq
 }
 
 } // namespace ezd

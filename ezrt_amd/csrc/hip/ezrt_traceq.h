@@ -421,7 +421,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
   }
 
   const unsigned long long rr = wave_sum(ctr.rays);
-  if (lane == 0 && rr) atomicAdd(&a.counters[EZRT_CTR_RAYS], rr);
+  if (lane == 0 && rr) atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_RAYS], rr);
   if (a.wave_log && lane == 0) {
     unsigned long long* w = a.wave_log + (size_t)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 8;
     w[0] = t_start;
@@ -435,10 +435,10 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
     const unsigned long long v1 = wave_sum(ctr.pops), v2 = wave_sum(ctr.inner), v3 = wave_sum(ctr.tris),
                              v4 = wave_sum(ctr.mats);
     if (lane == 0) {
-      atomicAdd(&a.counters[EZRT_CTR_NODE_POPS], v1);
-      atomicAdd(&a.counters[EZRT_CTR_INNER_POPS], v2);
-      atomicAdd(&a.counters[EZRT_CTR_TRI_TESTS], v3);
-      atomicAdd(&a.counters[EZRT_CTR_MAT_FETCH], v4);
+      atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_NODE_POPS], v1);
+      atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_INNER_POPS], v2);
+      atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_TRI_TESTS], v3);
+      atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_MAT_FETCH], v4);
     }
   }
 }

@@ -52,8 +52,8 @@ struct WfArgs {
   const float* sobol_tab;  // [frame - frame_first][8]: sobol(d, grayCode(frame + 1)), filled by raygen_kernel
   float* sobol_out;        // (the same table, as raygen_kernel writes it)
   uint32_t n_frames;       // frames of the chunk
-  uint32_t* n_defer;       // split shading (bounce >= 1): paths with a surface interaction, listed by shade_miss_kernel
-  uint32_t* defer_list;    // ... and shaded by shade_hit_kernel
+  uint32_t* defer_list;    // split shading: per workgroup of shade_miss_kernel, the paths with a surface interaction
+  uint32_t* defer_count;   // ... and how many; shaded by the same workgroup index of shade_hit_kernel
   uint32_t scatter;        // queue order of the primary rays: see queue_to_sample (1 = identity)
   uint32_t scatter_shift;  // scattered granule = 1 << scatter_shift slots (6: 8x8 sub-block, 8: 16x16 block, 5: 8x4 pixels)
 };
@@ -74,13 +74,14 @@ EZD void slot_to_pixel(const int2* blocks, int n_blocks, uint32_t slot, uint32_t
 // [lane]; taking queue position = sample slot would hand a wave pools of 256 rays from ONE 16x16
 // pixel block -- all cheap (sky) or all expensive (the Bunny), and the launch ends with the waves
 // that drew the expensive ones.  So the 8x8 sub-blocks of a frame are visited in a scattered
-// order, sub-block (r * scatter) mod n_sub at position r (scatter coprime to n_sub): a pool is four
+// order, sub-block (r * scatter) mod n_sub at position r (scatter ~ 2531, coprime to n_sub): a pool is four
 // sub-blocks from distant parts of the image and every pool costs about the same.
 EZD uint32_t queue_to_sample(uint32_t qslot, uint32_t n_blocks, uint32_t scatter, uint32_t sh = 6u) {
   const uint32_t n_sub = (n_blocks * 256u) >> sh; // granules of 1 << sh slots per frame
   const uint32_t q = qslot >> sh;
   const uint32_t fk = q / n_sub, r = q - fk * n_sub;
-  const uint32_t r2 = (uint32_t)(((unsigned long long)r * scatter) % n_sub);
+  const uint32_t r2 = (r * scatter) % n_sub; // 32-bit: the host keeps n_sub <= 2^20 and scatter < 2^12 here (a 64-bit
+                                             // modulo is a software loop: it was a third of raygen and of the primary shading)
   return ((fk * n_sub + r2) << sh) | (qslot & ((1u << sh) - 1u));
 }
 
@@ -187,12 +188,12 @@ struct ShadeOut {
   float cosine, pdf;
 };
 
-// One path through stage b.  PASS 0: everything inline (b == 0: primary hits are coherent).
-// PASS 1 (b > 0): everything but the surface interaction -- a path whose ray hit a triangle and that
+// One path through stage b (B0: b == 0, the path has no state yet).  PASS 0: everything inline.
+// PASS 1: everything but the surface interaction -- a path whose ray hit a triangle and that
 // is still alive returns true ("deferred") and touches nothing.  PASS 2: the deferred paths, regrouped
 // densely by the caller.  Bounce rays mostly leave the scene (90 % on C2), so without the regrouping
 // every wave ran the ~700-instruction surface code for a handful of its lanes.
-template <int INTEG, bool FULLCTR, int PASS>
+template <int INTEG, bool FULLCTR, int PASS, bool B0>
 EZD bool shade_path(const WfArgs& a, const uint32_t i, bool live, Counters& ctr, uint32_t& n_samples, ShadeOut& o) {
   constexpr bool P5TRI = (INTEG >= 50);
   constexpr bool MIS = (INTEG == EZRT_INTEGRATOR_P5_MIS);
@@ -211,13 +212,13 @@ EZD bool shade_path(const WfArgs& a, const uint32_t i, bool live, Counters& ctr,
   // round trip) instead of discovering them one branch at a time
   const uint32_t ii = live ? i : 0u;
   const uint32_t rslot = (b == 0 || !MIS) ? ii : (2u * ii + 1u);
-  const float4 rd4 = a.rq_in.d[rslot];
-  const int2 h = a.hits[rslot];
+  float4 rd4 = a.rq_in.d[rslot];
+  int2 h = a.hits[rslot];
   float4 ro4 = make_float4(p.eye[0], p.eye[1], p.eye[2], 0.0f);
   float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, s3 = s0, s4 = s0;
   int2 sh = make_int2(-1, 0);
-  if (PASS != 0) {
-    ro4 = a.rq_in.o[rslot];
+  if (!B0) {
+    if (PASS != 1) ro4 = a.rq_in.o[rslot]; // (only a surface interaction needs the ray origin)
     s3 = a.st_in.s3[ii];
     s0 = a.st_in.s0[ii];
     s1 = a.st_in.s1[ii];
@@ -227,20 +228,39 @@ EZD bool shade_path(const WfArgs& a, const uint32_t i, bool live, Counters& ctr,
       sh = a.hits[2u * ii];
     }
   }
+  // Pin the loads here: left alone, the compiler sinks every one of them into the branch that first uses
+  // it and narrows it to the component used there (rd4.w, then h.x, then rd4.xyz ...), i.e. a chain of
+  // three or four dependent memory round trips per path instead of one.
+#define EZ_PIN4(v) asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w))
+  EZ_PIN4(rd4);
+  asm volatile("" : "+v"(h.x), "+v"(h.y));
+  if (!B0) {
+    if (PASS != 1) EZ_PIN4(ro4);
+    EZ_PIN4(s0);
+    EZ_PIN4(s1);
+    EZ_PIN4(s2);
+    EZ_PIN4(s3);
+    if (MIS) {
+      EZ_PIN4(s4);
+      asm volatile("" : "+v"(sh.x), "+v"(sh.y));
+    }
+  }
+#undef EZ_PIN4
   bool done = false;
   if (!live) return false;
   f3 colour = mk(0, 0, 0);
   const f3 rd = mk(rd4.x, rd4.y, rd4.z);
-  if (PASS == 0) {
+  if (B0) {
     sslot = queue_to_sample(i, (uint32_t)a.n_blocks, a.scatter, a.scatter_shift);
     if (rd4.w == 0.0f) {
       live = false; // pixel not owned by this shard
     } else {
-      n_samples = n_samples + 1;
+      if (PASS != 2) n_samples = n_samples + 1;
       if (h.x < 0) { // primary miss: P5/fsh:931-933
         colour = hdr_color<FULLCTR>(sc, rd, p.env_clamp, ctr);
         done = true;
       } else {
+        if (PASS == 1) return true; // surface interaction: shaded in dense waves (shade_hit_kernel)
         shade_point<P5TRI>(sc, h.x, __int_as_float(h.y), mk(ro4.x, ro4.y, ro4.z), rd, hit);
         Le0 = hit.m.emissive;
         { // RNG state after the two anti-aliasing draws of ray generation (P5/fsh:315-318, 920-921)
@@ -411,55 +431,76 @@ EZD void shade_emit(const WfArgs& a, const ShadeOut& o, uint32_t* alloc_lds) {
   }
 }
 
-// Split shading of bounce >= 1 (split_shade): bounce rays mostly leave the scene, and everything a leaving
-// path needs (state loads, environment lookup, sample store) fits in a few dozen registers -- so that part
-// runs as its own kernel at twice the occupancy of the full shading kernel and lists the paths with a
-// surface interaction, which a second kernel then shades in dense waves.
-template <int INTEG, bool FULLCTR>
+// Split shading (split_shade): most paths of a stage leave the scene, and everything a leaving path
+// needs (state loads, environment lookup, sample store) fits in 45 registers -- so that part runs as
+// its own kernel at twice the occupancy of the full shading kernel, and lists the paths with a surface
+// interaction, which a second kernel then shades in dense waves.  The list is per workgroup (workgroup
+// k of the second kernel takes the list of workgroup k of the first): no global atomic and no barrier
+// in the first kernel -- one list-tail atomic per 512 paths was 32 k atomics on the primary stage, four
+// times what the counter sustains in the time the kernel needs.
+template <int INTEG, bool FULLCTR, bool B0>
 __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MISS_WAVES) void shade_miss_kernel(WfArgs a) {
-  __shared__ uint32_t alloc_lds[SHADE_BLOCK / 64 + 1];
-  const uint32_t n_in = *a.n_in;
+  __shared__ uint32_t list_tail;
+  const uint32_t n_in = B0 ? a.n_slots : *a.n_in;
   const uint32_t stride = gridDim.x * SHADE_BLOCK;
-  const uint32_t n_round = (n_in + stride - 1) / stride * stride;
+  const uint32_t iters = (n_in + stride - 1) / stride;
+  uint32_t* list = a.defer_list + (size_t)blockIdx.x * iters * SHADE_BLOCK; // this workgroup's region
+  if (threadIdx.x == 0) list_tail = 0u;
+  __syncthreads();
   Counters ctr = {0, 0, 0, 0, 0, 0, 0};
   uint32_t n_samples = 0;
-  for (uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x; i < n_round; i += stride) {
+  const int lane = threadIdx.x & 63;
+  for (uint32_t k = 0, i = blockIdx.x * SHADE_BLOCK + threadIdx.x; k < iters; k++, i += stride) {
     ShadeOut o;
-    const bool deferred = shade_path<INTEG, FULLCTR, 1>(a, i, i < n_in, ctr, n_samples, o);
-    const uint32_t k = block_alloc(a.n_defer, deferred, alloc_lds);
-    if (deferred) a.defer_list[k] = i;
+    const bool deferred = shade_path<INTEG, FULLCTR, 1, B0>(a, i, i < n_in, ctr, n_samples, o);
+    const unsigned long long m = ballot(deferred);
+    if (m) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&list_tail, (uint32_t)__popcll(m)); // LDS
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      if (deferred) list[base + lane_rank(m)] = i;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) a.defer_count[blockIdx.x] = list_tail;
+  if (B0) {
+    unsigned long long sn = wave_sum(n_samples);
+    if (lane == 0 && sn) atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_SAMPLES], sn);
   }
   if (FULLCTR) {
-    const int lane = threadIdx.x & 63;
     unsigned long long v5 = wave_sum(ctr.envmap), v6 = wave_sum(ctr.envcache);
     if (lane == 0) {
-      atomicAdd(&a.counters[EZRT_CTR_ENV_MAP], v5);
-      atomicAdd(&a.counters[EZRT_CTR_ENV_CACHE], v6);
+      atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_ENV_MAP], v5);
+      atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_ENV_CACHE], v6);
     }
   }
 }
 
-template <int INTEG, bool FULLCTR>
+// launched with the grid of shade_miss_kernel
+template <int INTEG, bool FULLCTR, bool B0>
 __global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_hit_kernel(WfArgs a) {
   __shared__ uint32_t alloc_lds[SHADE_BLOCK / 64 + 1];
   constexpr bool MIS = (INTEG == EZRT_INTEGRATOR_P5_MIS);
-  const uint32_t n_in = *a.n_defer;
+  const uint32_t n_in = B0 ? a.n_slots : *a.n_in;
   const uint32_t stride = gridDim.x * SHADE_BLOCK;
-  const uint32_t n_round = (n_in + stride - 1) / stride * stride;
+  const uint32_t iters = (n_in + stride - 1) / stride;
+  const uint32_t* list = a.defer_list + (size_t)blockIdx.x * iters * SHADE_BLOCK;
+  const uint32_t cnt = a.defer_count[blockIdx.x];
   Counters ctr = {0, 0, 0, 0, 0, 0, 0};
   uint32_t n_samples = 0;
-  for (uint32_t j = blockIdx.x * SHADE_BLOCK + threadIdx.x; j < n_round; j += stride) {
+  for (uint32_t j0 = 0; j0 < cnt; j0 += SHADE_BLOCK) { // (workgroup-uniform trip count: barriers inside)
+    const uint32_t j = j0 + threadIdx.x;
     ShadeOut o;
     o.emit = false;
-    if (j < n_in) shade_path<INTEG, FULLCTR, 2>(a, a.defer_list[j], true, ctr, n_samples, o);
+    if (j < cnt) shade_path<INTEG, FULLCTR, 2, B0>(a, list[j], true, ctr, n_samples, o);
     shade_emit<MIS>(a, o, alloc_lds);
   }
   if (FULLCTR) {
     const int lane = threadIdx.x & 63;
     unsigned long long v5 = wave_sum(ctr.envmap), v6 = wave_sum(ctr.envcache);
     if (lane == 0) {
-      atomicAdd(&a.counters[EZRT_CTR_ENV_MAP], v5);
-      atomicAdd(&a.counters[EZRT_CTR_ENV_CACHE], v6);
+      atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_ENV_MAP], v5);
+      atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_ENV_CACHE], v6);
     }
   }
 }
@@ -479,10 +520,10 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_kernel(WfArgs a) {
   for (uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x; i < n_round; i += stride) {
     ShadeOut o;
     if (b == 0) {
-      shade_path<INTEG, FULLCTR, 0>(a, i, i < n_in, ctr, n_samples, o);
+      shade_path<INTEG, FULLCTR, 0, true>(a, i, i < n_in, ctr, n_samples, o);
       shade_emit<MIS>(a, o, alloc_lds);
     } else {
-      const bool deferred = shade_path<INTEG, FULLCTR, 1>(a, i, i < n_in, ctr, n_samples, o);
+      const bool deferred = shade_path<INTEG, FULLCTR, 1, false>(a, i, i < n_in, ctr, n_samples, o);
       uint32_t n_def = 0;
       const uint32_t k = block_rank(deferred, alloc_lds, n_def);
       if (deferred) defer_list[k] = i;
@@ -490,19 +531,19 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_kernel(WfArgs a) {
       const bool has = threadIdx.x < n_def; // (n_def <= SHADE_BLOCK: one dense round)
       const uint32_t j = has ? defer_list[threadIdx.x] : 0u;
       o.emit = false;
-      if (has) shade_path<INTEG, FULLCTR, 2>(a, j, true, ctr, n_samples, o);
+      if (has) shade_path<INTEG, FULLCTR, 2, false>(a, j, true, ctr, n_samples, o);
       shade_emit<MIS>(a, o, alloc_lds);
     }
   }
 
   const int lane = threadIdx.x & 63;
   unsigned long long s = wave_sum(n_samples);
-  if (lane == 0 && s) atomicAdd(&a.counters[EZRT_CTR_SAMPLES], s);
+  if (lane == 0 && s) atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_SAMPLES], s);
   if (FULLCTR) {
     unsigned long long v5 = wave_sum(ctr.envmap), v6 = wave_sum(ctr.envcache);
     if (lane == 0) {
-      atomicAdd(&a.counters[EZRT_CTR_ENV_MAP], v5);
-      atomicAdd(&a.counters[EZRT_CTR_ENV_CACHE], v6);
+      atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_ENV_MAP], v5);
+      atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_ENV_CACHE], v6);
     }
   }
 }
