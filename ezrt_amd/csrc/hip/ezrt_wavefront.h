@@ -409,11 +409,17 @@ EZD bool shade_path(const WfArgs& a, const uint32_t i, bool live, Counters& ctr,
   return false;
 }
 
+template <bool MIS>
+EZD void shade_store(const WfArgs& a, const ShadeOut& o, const uint32_t k);
 // compaction of the surviving paths into the next queue: one ballot per wave, one atomic per workgroup
 template <bool MIS>
 EZD void shade_emit(const WfArgs& a, const ShadeOut& o, uint32_t* alloc_lds) {
   const uint32_t k = block_alloc(a.n_out, o.emit, alloc_lds);
   if (!o.emit) return;
+  shade_store<MIS>(a, o, k);
+}
+template <bool MIS>
+EZD void shade_store(const WfArgs& a, const ShadeOut& o, const uint32_t k) {
   a.st_out.s0[k] = make_float4(o.history.x, o.history.y, o.history.z, o.cosine);
   a.st_out.s1[k] = make_float4(o.Lo.x, o.Lo.y, o.Lo.z, o.pdf);
   a.st_out.s2[k] = make_float4(o.f_r.x, o.f_r.y, o.f_r.z, __uint_as_float(o.sslot));
@@ -488,12 +494,27 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_hit_kernel(WfArgs a) {
   const uint32_t cnt = a.defer_count[blockIdx.x];
   Counters ctr = {0, 0, 0, 0, 0, 0, 0};
   uint32_t n_samples = 0;
-  for (uint32_t j0 = 0; j0 < cnt; j0 += SHADE_BLOCK) { // (workgroup-uniform trip count: barriers inside)
-    const uint32_t j = j0 + threadIdx.x;
-    ShadeOut o;
-    o.emit = false;
-    if (j < cnt) shade_path<INTEG, FULLCTR, 2, B0>(a, list[j], true, ctr, n_samples, o);
-    shade_emit<MIS>(a, o, alloc_lds);
+  if (!MIS) {
+    // Without MIS every surface interaction below the last bounce continues its path (P5/fsh:767-804 has
+    // no early exit after a hit), so the workgroup reserves its cnt queue slots with ONE atomic and path j
+    // of the list goes to slot base + j: no compaction, no barrier in the loop.
+    if (cnt == 0u) return;
+    if (threadIdx.x == 0) alloc_lds[0] = (a.bounce < a.p.max_bounce) ? atomicAdd(a.n_out, cnt) : 0u;
+    __syncthreads();
+    const uint32_t base = alloc_lds[0];
+    for (uint32_t j = threadIdx.x; j < cnt; j += SHADE_BLOCK) {
+      ShadeOut o;
+      shade_path<INTEG, FULLCTR, 2, B0>(a, list[j], true, ctr, n_samples, o);
+      if (o.emit) shade_store<MIS>(a, o, base + j);
+    }
+  } else {
+    for (uint32_t j0 = 0; j0 < cnt; j0 += SHADE_BLOCK) { // (workgroup-uniform trip count: barriers inside)
+      const uint32_t j = j0 + threadIdx.x;
+      ShadeOut o;
+      o.emit = false;
+      if (j < cnt) shade_path<INTEG, FULLCTR, 2, B0>(a, list[j], true, ctr, n_samples, o);
+      shade_emit<MIS>(a, o, alloc_lds);
+    }
   }
   if (FULLCTR) {
     const int lane = threadIdx.x & 63;
