@@ -255,15 +255,19 @@ def test_schedule_knobs_never_change_results(hip, bunny_small):
     """ezrt_set_option only reschedules the same arithmetic: every combination is bit-identical."""
     sg = bunny_small.upload(hip)
     eye, cam = S.camera(0, 0, 4)
-    p = trace.make_params(160, 120, eye, cam, 51, 2, spp=3)
-    ref = sg.render(p)
-    for opts in ({"megakernel": 1}, {"packet": 1}, {"packet": 1, "packet_budget": 8}, {"leaf_threshold": 1},
-                 {"leaf_threshold": 64}, {"pool_max": 8}, {"pool_div": 16, "pool_max": 2048}, {"trace_wps": 4},
-                 {"trace_wps": 6}, {"trace_wps": 8}, {"lds_nodes": 0}, {"lds_nodes": 7}):
-        s2 = bunny_small.upload(hip)
-        for k, v in opts.items():
-            s2.set_option(k, v)
-        assert np.array_equal(_bits(s2.render(p)), _bits(ref)), opts
+    for integ, mb in ((51, 2), (50, 3)):
+        p = trace.make_params(160, 120, eye, cam, integ, mb, spp=3)
+        ref = sg.render(p)
+        for opts in ({"megakernel": 1}, {"packet": 1}, {"packet": 1, "packet_budget": 8}, {"leaf_threshold": 1},
+                     {"leaf_threshold": 64}, {"pool_max": 8}, {"pool_div": 16, "pool_max": 2048}, {"trace_wps": 4},
+                     {"trace_wps": 5}, {"trace_wps": 8}, {"lds_nodes": 0}, {"lds_nodes": 7}, {"steal": 0},
+                     {"scatter": 0}, {"scatter": 5}, {"scatter": 8}, {"static_pct": 0}, {"static_pct": 90},
+                     {"refill_min": 1}, {"refill_min": 64}, {"split_shade": 0}, {"split_shade": 1}, {"pipes": 2},
+                     {"pipes": 2, "sub_frames": 1}):
+            s2 = bunny_small.upload(hip)
+            for k, v in opts.items():
+                s2.set_option(k, v)
+            assert np.array_equal(_bits(s2.render(p)), _bits(ref)), (integ, opts)
     with pytest.raises(trace.TraceError, match="unknown option"):
         sg.set_option("no_such_knob", 1)
 
