@@ -64,7 +64,7 @@ struct Tuning {
   int packet_budget = 48;  // steps after which a packet hands its rays to the per-lane kernel
   int leaf_threshold = 24; // lanes waiting at a leaf that trigger the triangle phase
   int pool_div = 1;        // ray-index pool = clamp(n_rays / (n_waves * pool_div), 8, pool_max)
-  int pool_max = 256;
+  int pool_max = 128;      // rays per dynamic reservation (two 8x8 sub-blocks; affordable since the reservations spread over 8 counters)
   int trace_wps = 6;       // traceq_kernel register budget: waves per SIMD (4, 5, 6 or 8); 6 = 80 VGPRs (8 B of
                            // scratch) and fewer tree records in LDS, still +3.6 % over 5 since the loop got leaner
   int lds_nodes = 1 << 20; // cap on top-of-tree records staged in LDS
@@ -114,6 +114,7 @@ struct Pipe {
   DevBuf<uint32_t> qcounts; // [0..63] path counts per stage, [64..99] trace queue heads, [100..115] debug,
                             // [120] redo count, [121] redo queue head
   DevBuf<uint32_t> redo_slots;
+  DevBuf<uint32_t> qheads;      // traceq reservation counters: [launch slot][TRACE_HEADS][TRACE_HEAD_STRIDE]
   DevBuf<uint32_t> defer_list;  // split shading: paths with a surface interaction, per workgroup
   DevBuf<uint32_t> defer_count;
   hipStream_t stream = nullptr;  // own stream (pipelined calls only)
@@ -336,6 +337,9 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
   }
   // [0..63] paths per stage, [64..99] queue heads, [100..119] debug, [120,121] packet redo,
   // [128..] redo counts per stage, [192..] redo queue heads per stage
+  constexpr size_t HEAD_SLOT = (size_t)TRACE_HEADS * TRACE_HEAD_STRIDE; // launch slots: stage b, redo 40 + b, packet redo 80
+  HIP_TRY(pp.qheads.ensure(81 * HEAD_SLOT));
+  HIP_TRY(hipMemsetAsync(pp.qheads.p, 0, 81 * HEAD_SLOT * sizeof(uint32_t), st));
   HIP_TRY(pp.qcounts.ensure(320));
   HIP_TRY(hipMemsetAsync(pp.qcounts.p, 0, 320 * sizeof(uint32_t), st));
   HIP_TRY(pp.defer_list.ensure(n_slots + (size_t)2048 * 1024)); // per-workgroup regions: iterations x SHADE_BLOCK each
@@ -440,7 +444,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     t.origin[0] = p->eye[0];
     t.origin[1] = p->eye[1];
     t.origin[2] = p->eye[2];
-    t.head = pp.qcounts.p + 64 + b;
+    t.head = pp.qheads.p + (size_t)b * HEAD_SLOT;
     t.counters = s->counters.p;
     t.leaf_threshold = leaf_thr;
     t.static_pct = (uint32_t)(tu.static_pct < 0 ? 0 : (tu.static_pct > 95 ? 95 : tu.static_pct));
@@ -499,7 +503,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
       s->n_trace_launches++;
       t.slot_map = pp.redo_slots.p;
       t.n_paths = pp.qcounts.p + 120;
-      t.head = pp.qcounts.p + 121;
+      t.head = pp.qheads.p + (size_t)80 * HEAD_SLOT;
       t.rays_per_path = 1u;
       t.steal = 0u;
       t.redo_flag = nullptr;
@@ -513,7 +517,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
         r.slot_map = pp.redo_slots.p;
         r.n_paths = pp.qcounts.p + 128 + b;
         r.rays_per_path = 1u;
-        r.head = pp.qcounts.p + 192 + b;
+        r.head = pp.qheads.p + (size_t)(40 + b) * HEAD_SLOT;
         r.dbg = nullptr;
         r.wave_log = nullptr;
         launch_traceq(r, true);

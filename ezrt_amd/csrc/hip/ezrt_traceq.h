@@ -26,6 +26,8 @@ namespace ezd {
 
 constexpr uint32_t REF_NONE = 0xffffffffu; // a lane without a ray (every predicate below is ONE compare on `ref`)
 constexpr uint32_t REF_DONE = 0xfffffffeu; // traversal finished, {t, triangle} not stored yet (done in the batched refill)
+constexpr uint32_t TRACE_HEADS = 8;        // reservation counters per queue
+constexpr uint32_t TRACE_HEAD_STRIDE = 16; // words between them (64 bytes)
 constexpr uint32_t TRACE_POOL_MIN = 8; // smallest reservation: short queues are spread over every wave
 
 struct RayQueue {
@@ -41,7 +43,8 @@ struct TraceQArgs {
   uint32_t rays_per_path;
   uint32_t const_origin;   // 1: every ray of this queue starts at `origin` (primary rays); rq.o is not read
   float origin[3];
-  uint32_t* head;          // head of the dynamically reserved part of the queue (device, zeroed per launch)
+  uint32_t* head;          // TRACE_HEADS counters (TRACE_HEAD_STRIDE words apart) of the dynamically reserved part of
+                           // the queue (device, zeroed per launch)
   unsigned long long* counters;
   int32_t leaf_threshold;  // lanes waiting at a leaf that trigger the triangle phase
   uint32_t refill_min;     // lanes that must be free before the wave runs its refill code
@@ -197,8 +200,15 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
             base = (round * n_waves + (wave_id + round * 1223u) % n_waves) * pool_size;
             round++;
           } else if (static_total < n_rays) {
-            if (lane == 0) base = atomicAdd(a.head, pool_size);
-            base = static_total + __shfl(base, 0, 64);
+            // dynamic pool p belongs to counter p % TRACE_HEADS; a wave only ever asks its own counter (every
+            // counter has ~n_waves / TRACE_HEADS clients that keep asking until it runs dry, so no pool is
+            // left behind): the reservations of a stage spread over eight words instead of queueing on one
+            const uint32_t h = wave_id % TRACE_HEADS;
+            uint32_t k = 0;
+            if (lane == 0) k = atomicAdd(a.head + h * TRACE_HEAD_STRIDE, 1u);
+            k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+            const unsigned long long off = (unsigned long long)(k * TRACE_HEADS + h) * pool_size;
+            base = off < (unsigned long long)(n_rays - static_total) ? static_total + (uint32_t)off : n_rays;
           }
           const uint32_t left = pool_end - pool_next; // hand out the old pool's rest first
           uint32_t take = cnt - left;
