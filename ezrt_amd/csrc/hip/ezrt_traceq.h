@@ -93,9 +93,8 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
   // queues of up to n_waves * pool_max rays -- 5120 waves bumping one counter would cost ~60 us per
   // round, the whole budget of a late bounce (one word sustains ~88 atomics/us chip-wide) -- and,
   // with the blocks of a frame queued most-expensive-first, every wave gets the same mix of expensive
-  // and cheap pools.  Indices beyond the static region are reserved dynamically, one atomic per pool.
-  // (Smaller pools for the queue's last stretch, and eight interleaved counters with guided pool
-  // sizes, were tried: no gain.)
+  // and cheap pools.  Indices beyond the static region are reserved dynamically, one atomic per pool, on eight counters.
+  // (Smaller pools only for the queue's last stretch, and guided pool sizes, were tried: no gain.)
   uint32_t pool_size = (n_rays + n_waves * a.pool_div - 1) / (n_waves * a.pool_div);
   pool_size = pool_size > a.pool_max ? a.pool_max : (pool_size < TRACE_POOL_MIN ? TRACE_POOL_MIN : pool_size);
   uint32_t static_rounds = (uint32_t)(((unsigned long long)n_rays * a.static_pct) / (100ull * n_waves * pool_size));
