@@ -130,11 +130,33 @@ EZD float hit_aabb(f3 S, f3 inv, f3 AA, f3 BB) {
 // no NaN can arise when the ray's origin and 1/direction are finite (finite box minus finite origin
 // times a finite factor is finite or +-inf, never NaN).  Callers use it only for such rays
 // (ray_is_tame) and fall back to hit_aabb otherwise, so decisions stay bit-identical.
+// (v_min/v_max straight from inline asm: through fminf/fmaxf the compiler first canonicalises every operand
+// with a v_max_f32 x, x -- six more instructions per inner step of a loop that is bound by VALU issue)
+EZD float hw_min(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+EZD float hw_max(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+EZD float hw_min3(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+EZD float hw_max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 EZD float hit_aabb_tame(f3 S, f3 inv, f3 AA, f3 BB) {
   f3 f = (BB - S) * inv;
   f3 n = (AA - S) * inv;
-  float t1 = __builtin_fminf(__builtin_fmaxf(f.x, n.x), __builtin_fminf(__builtin_fmaxf(f.y, n.y), __builtin_fmaxf(f.z, n.z)));
-  float t0 = __builtin_fmaxf(__builtin_fminf(f.x, n.x), __builtin_fmaxf(__builtin_fminf(f.y, n.y), __builtin_fminf(f.z, n.z)));
+  float t1 = hw_min3(hw_max(f.x, n.x), hw_max(f.y, n.y), hw_max(f.z, n.z));
+  float t0 = hw_max3(hw_min(f.x, n.x), hw_min(f.y, n.y), hw_min(f.z, n.z));
   return (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
 }
 EZD bool ray_is_tame(f3 S, f3 inv) {
