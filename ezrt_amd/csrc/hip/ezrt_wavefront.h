@@ -263,7 +263,8 @@ EZD bool shade_path(const WfArgs& a, const uint32_t i, bool live, Counters& ctr,
         if (PASS == 1) return true; // surface interaction: shaded in dense waves (shade_hit_kernel)
         shade_point<P5TRI>(sc, h.x, __int_as_float(h.y), mk(ro4.x, ro4.y, ro4.z), rd, hit);
         Le0 = hit.m.emissive;
-        { // RNG state after the two anti-aliasing draws of ray generation (P5/fsh:315-318, 920-921)
+        if (INTEG != EZRT_INTEGRATOR_P5_SOBOL) { // (integrator 50 draws nothing after ray generation: Sobol + CP only)
+          // RNG state after the two anti-aliasing draws of ray generation (P5/fsh:315-318, 920-921)
           int x0, y0;
           uint32_t f0;
           slot_to_pixel(a.blocks, a.n_blocks, sslot, a.frame_first, x0, y0, f0);
