@@ -152,6 +152,21 @@ EZD float hw_max3(float a, float b, float c) {
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
+// the two slab tests on boxes already translated by the ray origin (see TraceQArgs.inner_rel)
+EZD float hit_aabb_rel(f3 inv, f3 AA, f3 BB) {
+  f3 f = BB * inv;
+  f3 n = AA * inv;
+  float t1 = ez_min(ez_max(f.x, n.x), ez_min(ez_max(f.y, n.y), ez_max(f.z, n.z)));
+  float t0 = ez_max(ez_min(f.x, n.x), ez_max(ez_min(f.y, n.y), ez_min(f.z, n.z)));
+  return (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
+}
+EZD float hit_aabb_tame_rel(f3 inv, f3 AA, f3 BB) {
+  f3 f = BB * inv;
+  f3 n = AA * inv;
+  float t1 = hw_min3(hw_max(f.x, n.x), hw_max(f.y, n.y), hw_max(f.z, n.z));
+  float t0 = hw_max3(hw_min(f.x, n.x), hw_min(f.y, n.y), hw_min(f.z, n.z));
+  return (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
+}
 EZD float hit_aabb_tame(f3 S, f3 inv, f3 AA, f3 BB) {
   f3 f = (BB - S) * inv;
   f3 n = (AA - S) * inv;

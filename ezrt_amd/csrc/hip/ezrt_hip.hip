@@ -77,6 +77,7 @@ struct Tuning {
   int refill_min = 16;     // free lanes a wave waits for before it runs its refill code (publish results, adopt the
                            // prefetched ray, prefetch the next): wave-wide code for per-lane events, so batch it (+9 %)
   int split_shade = 2;     // leaving paths and surface interactions shaded by two kernels: 1 from bounce 1 on, 2 always
+  int rel_boxes = 1;       // primary rays traverse boxes already translated by the eye
   int steal = 1;           // intra-wave work stealing in traceq_kernel (+ a redo launch for exact ties)
   int debug_stages = 0;    // print per-stage queue sizes (synchronises)
 };
@@ -88,7 +89,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel}, {"packet", &T
                               {"packet_budget", &Tuning::packet_budget}, {"leaf_threshold", &Tuning::leaf_threshold},
                               {"pool_div", &Tuning::pool_div}, {"pool_max", &Tuning::pool_max},
                               {"trace_wps", &Tuning::trace_wps}, {"lds_nodes", &Tuning::lds_nodes},
-                              {"steal", &Tuning::steal}, {"split_shade", &Tuning::split_shade}, {"refill_min", &Tuning::refill_min}, {"static_pct", &Tuning::static_pct}, {"pipes", &Tuning::pipes}, {"sub_frames", &Tuning::sub_frames}, {"scatter", &Tuning::scatter}, {"debug_stages", &Tuning::debug_stages}};
+                              {"steal", &Tuning::steal}, {"rel_boxes", &Tuning::rel_boxes}, {"split_shade", &Tuning::split_shade}, {"refill_min", &Tuning::refill_min}, {"static_pct", &Tuning::static_pct}, {"pipes", &Tuning::pipes}, {"sub_frames", &Tuning::sub_frames}, {"scatter", &Tuning::scatter}, {"debug_stages", &Tuning::debug_stages}};
 Tuning tuning_from_env() {
   Tuning t;
   for (const TuningName& k : kTuning) {
@@ -115,6 +116,7 @@ struct Pipe {
                             // [120] redo count, [121] redo queue head
   DevBuf<uint32_t> redo_slots;
   DevBuf<uint32_t> qheads;      // traceq reservation counters: [launch slot][TRACE_HEADS][TRACE_HEAD_STRIDE]
+  DevBuf<float4> inner_rel;     // inner records translated by -eye (primary rays)
   DevBuf<uint32_t> defer_list;  // split shading: paths with a surface interaction, per workgroup
   DevBuf<uint32_t> defer_count;
   hipStream_t stream = nullptr;  // own stream (pipelined calls only)
@@ -407,6 +409,11 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
   a.sobol_tab = pp.sobol_tab.p;
   a.sobol_out = pp.sobol_tab.p;
   a.n_frames = nf;
+  if (s->tune.rel_boxes && s->n_inner > 0) {
+    HIP_TRY(pp.inner_rel.ensure((size_t)s->n_inner * 4));
+    hipLaunchKernelGGL(inner_rel_kernel, dim3((unsigned)((s->n_inner + 255) / 256)), dim3(256), 0, st, s->inner.p, s->n_inner,
+                       p->eye[0], p->eye[1], p->eye[2], pp.inner_rel.p);
+  }
   hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((n_slots + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, a);
 
   const size_t lds = stack_lds_bytes(s);
@@ -441,6 +448,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     t.n_paths = pp.qcounts.p + b;
     t.rays_per_path = (mis && b > 0) ? 2u : 1u;
     t.const_origin = b == 0 ? 1u : 0u;
+    t.inner_rel = (b == 0 && tu.rel_boxes && s->n_inner > 0) ? pp.inner_rel.p : nullptr;
     t.origin[0] = p->eye[0];
     t.origin[1] = p->eye[1];
     t.origin[2] = p->eye[2];

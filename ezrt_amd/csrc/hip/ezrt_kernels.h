@@ -274,6 +274,17 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(AccumArgs a) {
   a.accum[pix] = make_float4(mean.x, mean.y, mean.z, 1.0f);
 }
 
+// inner records with both child boxes translated by -S (S = the eye): what hitAABB subtracts on every visit
+__global__ void inner_rel_kernel(const float4* inner, int n_inner, float sx, float sy, float sz, float4* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_inner) return;
+  const float4 q0 = inner[i * 4], q1 = inner[i * 4 + 1], q2 = inner[i * 4 + 2];
+  out[i * 4] = make_float4(q0.x - sx, q0.y - sy, q0.z - sz, q0.w - sx);
+  out[i * 4 + 1] = make_float4(q1.x - sy, q1.y - sz, q1.z - sx, q1.w - sy);
+  out[i * 4 + 2] = make_float4(q2.x - sz, q2.y - sx, q2.z - sy, q2.w - sz);
+  out[i * 4 + 3] = inner[i * 4 + 3];
+}
+
 __global__ void sobol_kernel(uint32_t index0, int n, int n_dims, float* out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * n_dims) return;

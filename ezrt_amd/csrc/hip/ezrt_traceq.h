@@ -43,6 +43,9 @@ struct TraceQArgs {
   uint32_t rays_per_path;
   uint32_t const_origin;   // 1: every ray of this queue starts at `origin` (primary rays); rq.o is not read
   float origin[3];
+  const float4* inner_rel; // const_origin only (or NULL): sc.inner with every box already translated by -origin, i.e.
+                           // (AA - S, BB - S) evaluated once per record instead of once per visit -- the same fp32
+                           // subtractions, so the same bits
   uint32_t* head;          // TRACE_HEADS counters (TRACE_HEAD_STRIDE words apart) of the dynamically reserved part of
                            // the queue (device, zeroed per launch)
   unsigned long long* counters;
@@ -84,7 +87,9 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
   if (n_rays == 0) return; // (redo launches are normally empty)
   int* wsrc = lds_stack + a.stack_entries * BLOCK + (threadIdx.x >> 6) * 64;
   float4* lds_nodes = reinterpret_cast<float4*>(lds_stack + a.stack_entries * BLOCK + BLOCK);
-  for (int k = threadIdx.x; k < a.lds_nodes * 4; k += BLOCK) lds_nodes[(k >> 2) * 5 + (k & 3)] = sc.inner[k];
+  const bool rel = a.inner_rel != nullptr;
+  const float4* inner = rel ? a.inner_rel : sc.inner;
+  for (int k = threadIdx.x; k < a.lds_nodes * 4; k += BLOCK) lds_nodes[(k >> 2) * 5 + (k & 3)] = inner[k];
   __syncthreads();
 
   const uint32_t n_waves = gridDim.x * (BLOCK / 64);
@@ -312,14 +317,22 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
         q2 = make_float4(w2.x, w2.y, w2.z, w2.w);
         q3 = make_float4(w3.x, w3.y, w3.z, w3.w);
       } else {
-        const float4* r = sc.inner + (size_t)ref * 4;
+        const float4* r = inner + (size_t)ref * 4;
         q0 = r[0];
         q1 = r[1];
         q2 = r[2];
         q3 = r[3];
       }
       float d1, d2;
-      if (wave_wild) { // some lane's ray has a zero/NaN direction component: exact select form
+      if (rel) { // (wave-uniform) boxes relative to the common ray origin: no subtraction here
+        if (wave_wild) {
+          d1 = hit_aabb_rel(inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));
+          d2 = hit_aabb_rel(inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w));
+        } else {
+          d1 = hit_aabb_tame_rel(inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));
+          d2 = hit_aabb_tame_rel(inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w));
+        }
+      } else if (wave_wild) { // some lane's ray has a zero/NaN direction component: exact select form
         d1 = hit_aabb(S, inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));
         d2 = hit_aabb(S, inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w));
       } else {

@@ -263,7 +263,7 @@ def test_schedule_knobs_never_change_results(hip, bunny_small):
                      {"trace_wps": 5}, {"trace_wps": 8}, {"lds_nodes": 0}, {"lds_nodes": 7}, {"steal": 0},
                      {"scatter": 0}, {"scatter": 5}, {"scatter": 8}, {"static_pct": 0}, {"static_pct": 90},
                      {"refill_min": 1}, {"refill_min": 64}, {"split_shade": 0}, {"split_shade": 1}, {"pipes": 2},
-                     {"pipes": 2, "sub_frames": 1}):
+                     {"pipes": 2, "sub_frames": 1}, {"rel_boxes": 0}):
             s2 = bunny_small.upload(hip)
             for k, v in opts.items():
                 s2.set_option(k, v)
