@@ -295,3 +295,27 @@ def test_png_and_pfm_writers(tmp_path):
     n = struct.unpack(">I", raw[i - 4:i])[0]
     rows = np.frombuffer(zlib.decompress(raw[i + 4:i + 4 + n]), np.uint8).reshape(5, 1 + 7 * 3)
     assert np.array_equal(rows[:, 1:].reshape(5, 7, 3), q[::-1])     # top row first
+
+
+def test_scene_description_file_builds_the_canned_scene_on_the_host(bunny_small, tmp_path):
+    """ezrt_amd.render.build_scene (host builders only here): the P3 scene as JSON gives the arrays of the
+    canned scene; "median" selects buildBVH."""
+    from ezrt_amd import render
+    for name in ("bunny", "quad", "sphere"):
+        v, f = scenes.mesh(name)
+        (tmp_path / (name + ".obj")).write_bytes(scenes.obj_text(v, f))
+    desc = {"integrator": 51, "env": {"synthetic": True}, "bvh": {"builder": "sah", "leaf": 8}, "objects": [
+        {"obj": "bunny.obj", "smooth": True, "translate": [0.3, -1.6, 0], "scale": [1.5, 1.5, 1.5],
+         "material": {"defaults": "p4", "baseColor": [1, 1, 1]}},
+        {"obj": "quad.obj", "translate": [0, -1.4, 0], "scale": [18.83, 0.01, 18.83],
+         "material": {"defaults": "p4", "baseColor": [0.725, 0.71, 0.68]}},
+        {"obj": "sphere.obj", "translate": [0.0, 0.9, 0.0],
+         "material": {"defaults": "p4", "baseColor": [1, 1, 1], "emissive": [30, 20, 10]}}]}
+    b = render.build_scene(desc, str(tmp_path))
+    assert np.array_equal(b.tri, bunny_small.tri) and np.array_equal(b.nodes, bunny_small.nodes)
+    assert b.cache is not None and np.array_equal(b.cache, bunny_small.cache)
+    desc["bvh"] = {"builder": "median", "leaf": 4}
+    m = render.build_scene(desc, str(tmp_path))
+    n = m.nodes[1:, 3]
+    assert n.max() <= 4 and n[n > 0].sum() == b.tri.shape[0] and not np.array_equal(m.nodes[:20], b.nodes[:20])
+    assert render.material_from({"defaults": "p3", "roughness": 0.25}).to18()[10] == np.float32(0.25)
