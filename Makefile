@@ -3,6 +3,7 @@
 #   ezrt_amd/lib/libezrt_scene.so   host C++ scene build (no HIP dependency)
 #   ezrt_amd/lib/libezrt_hip.so     hand-written gfx950 kernels + the C ABI
 #   oracle/libezrt_oracle.so        CPU oracle (test infrastructure)
+#   oracle/_ref/libezrt_ref_p*.so   the reference's own host code compiled from /root/reference (when present)
 ROCM ?= /opt/rocm
 HIPCC ?= $(ROCM)/bin/hipcc
 CXX ?= g++
@@ -25,6 +26,7 @@ host: $(LIBDIR)/libezrt_scene.so
 hip: $(LIBDIR)/libezrt_hip.so
 oracle:
 	$(MAKE) -C oracle
+	@if [ -d /root/reference ]; then python3 oracle/ref_recipe/build_ref.py; fi
 
 $(LIBDIR)/libezrt_scene.so: $(HOST_SRC) include/ezrt_scene.hpp include/ezrt_scene_c.h include/ezrt_detmath.h
 	@mkdir -p $(LIBDIR)

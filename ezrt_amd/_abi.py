@@ -74,6 +74,7 @@ HOST_ABI = {
     "ezrt_host_read_obj_text": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64, c_float_p, c_float_p, C.c_int]),
     "ezrt_host_add_triangles": (C.c_int, [C.c_void_p, c_float_p, C.c_int]),
     "ezrt_host_build_bvh": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "ezrt_host_set_tie_order": (C.c_int, [C.c_int]),
     "ezrt_host_build_stats": (C.c_int, [C.c_void_p, c_int64_p]),
     "ezrt_host_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ezrt_host_encode": (C.c_int, [C.c_void_p, c_float_p, c_float_p]),

@@ -653,8 +653,10 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
     if (depth[(size_t)i] == 0) continue;
     HostNode h = decode_node(nodes, i);
     if (h.n <= 0) {
-      depth[(size_t)h.left] = depth[(size_t)i] + 1;
-      depth[(size_t)h.right] = depth[(size_t)i] + 1;
+      // caller arrays may reference a node from several parents (a DAG): the LDS stack must fit the
+      // DEEPEST path, so keep the maximum (ids are topologically ordered: one pass is exact)
+      depth[(size_t)h.left] = std::max(depth[(size_t)h.left], depth[(size_t)i] + 1);
+      depth[(size_t)h.right] = std::max(depth[(size_t)h.right], depth[(size_t)i] + 1);
     }
     if (depth[(size_t)i] > maxd) maxd = depth[(size_t)i];
   }
@@ -1042,16 +1044,22 @@ int ezrt_scene_stats(EzrtScene* s, int64_t out[6]) {
 }
 
 int ezrt_debug_math(int op, const float* a, const float* b, int n, float* out) {
-  if (!a || !out || n < 0 || op < 0 || op > 9) return fail(EZRT_ERR_INVALID, "bad argument");
+  if (!a || !out || n < 0 || op < 0 || op > 12) return fail(EZRT_ERR_INVALID, "bad argument");
   if (n == 0) return 0;
+  // ops 10-12 (intersector audit): a = n rays of 6 floats, b = n boxes of 6 / triangles of 9 floats
+  const size_t wa = op >= 10 ? 6 : 1, wb = op == 11 ? 9 : (op >= 10 ? 6 : 1);
+  if (op >= 10 && !b) return fail(EZRT_ERR_INVALID, "bad argument");
   DevBuf<float> da, db, dout;
-  HIP_TRY(da.ensure((size_t)n));
-  HIP_TRY(db.ensure((size_t)n));
+  HIP_TRY(da.ensure((size_t)n * wa));
+  HIP_TRY(db.ensure((size_t)n * wb));
   HIP_TRY(dout.ensure((size_t)n));
-  HIP_TRY(hipMemcpy(da.p, a, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
-  if (b) HIP_TRY(hipMemcpy(db.p, b, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(da.p, a, (size_t)n * wa * sizeof(float), hipMemcpyHostToDevice));
+  if (b) HIP_TRY(hipMemcpy(db.p, b, (size_t)n * wb * sizeof(float), hipMemcpyHostToDevice));
   else HIP_TRY(hipMemset(db.p, 0, (size_t)n * sizeof(float)));
-  hipLaunchKernelGGL(math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, op, da.p, db.p, n, dout.p);
+  if (op >= 10)
+    hipLaunchKernelGGL(isect_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, op, da.p, db.p, n, dout.p);
+  else
+    hipLaunchKernelGGL(math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, op, da.p, db.p, n, dout.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
   return 0;

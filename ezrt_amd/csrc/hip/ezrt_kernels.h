@@ -365,4 +365,34 @@ __global__ void math_kernel(int op, const float* a, const float* b, int n, float
   out[i] = r;
 }
 
+// Intersector audit (ezrt_debug_math ops 10-12): the device functions the traversal kernels call,
+// evaluated on caller-supplied operands so tests can compare them with the reference's C++ twins
+// (P2/main.cpp:212-238, 449-463) directly.  op 10 = hit_aabb (exact select form), 12 = hit_aabb_tame
+// (v_min3/v_max3 form; NaN for rays that are not tame = the caller must not have used it), 11 =
+// hit_triangle_t on the 48-B record ezrt_scene_create builds (unit plane normal precomputed with the
+// same fp32 operations), INF on a miss.
+__global__ void isect_kernel(int op, const float* a, const float* b, int n, float* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* r = a + 6 * (size_t)i;
+  f3 S = mk(r[0], r[1], r[2]), d = mk(r[3], r[4], r[5]);
+  if (op == 11) {
+    const float* t = b + 9 * (size_t)i;
+    float e1x = t[3] - t[0], e1y = t[4] - t[1], e1z = t[5] - t[2];
+    float e2x = t[6] - t[0], e2y = t[7] - t[1], e2z = t[8] - t[2];
+    float cx = e1y * e2z - e1z * e2y, cy = e1z * e2x - e1x * e2z, cz = e1x * e2y - e1y * e2x;
+    float inv = 1.0f / __builtin_sqrtf(cx * cx + cy * cy + cz * cz);
+    float4 g[3] = {make_float4(t[0], t[1], t[2], cx * inv), make_float4(t[3], t[4], t[5], cy * inv),
+                   make_float4(t[6], t[7], t[8], cz * inv)};
+    float tt;
+    out[i] = hit_triangle_t(g, S, d, tt) ? tt : INF;
+    return;
+  }
+  const float* q = b + 6 * (size_t)i;
+  f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  f3 AA = mk(q[0], q[1], q[2]), BB = mk(q[3], q[4], q[5]);
+  if (op == 10) out[i] = hit_aabb(S, inv, AA, BB);
+  else out[i] = ray_is_tame(S, inv) ? hit_aabb_tame(S, inv, AA, BB) : __uint_as_float(0x7fc00000u);
+}
+
 } // namespace ezd

@@ -140,6 +140,11 @@ int ezrt_host_build_bvh(EzrtHostScene* h, int method, int leaf_n) {
   return 0;
   EZ_CATCH
 }
+int ezrt_host_set_tie_order(int library_sort) {
+  if (library_sort != 0 && library_sort != 1) return fail(-1, "tie order must be 0 (stable) or 1 (library std::sort)");
+  setTieOrder(library_sort ? TieOrder::LibrarySort : TieOrder::Stable);
+  return 0;
+}
 int ezrt_host_build_stats(EzrtHostScene* h, int64_t out[3]) {
   if (!h || !out) return fail(-1, "NULL argument");
   out[0] = h->stats.inf_cap_nodes;

@@ -111,36 +111,36 @@ mat4 lookAt(vec3 eye, vec3 center, vec3 up) {
   return o;
 }
 mat4 inverse(const mat4& M) {
-  // cofactor expansion; a[r][c] row-major view of the column-major storage
-  float a[4][4];
+  // GLM's operand order (detail/func_matrix.inl, compute_inverse<4,4>): 2x2 sub-determinants shared
+  // between cofactors, columns scaled by 1/det.  Bit-identical to the reference's inverse(lookAt(..))
+  // on the same inputs, including the signs of zero entries (tests/test_ref_pin.py).
+  const float(*m)[4] = M.c; // m[col][row]
+  float c00 = m[2][2] * m[3][3] - m[3][2] * m[2][3], c02 = m[1][2] * m[3][3] - m[3][2] * m[1][3];
+  float c03 = m[1][2] * m[2][3] - m[2][2] * m[1][3], c04 = m[2][1] * m[3][3] - m[3][1] * m[2][3];
+  float c06 = m[1][1] * m[3][3] - m[3][1] * m[1][3], c07 = m[1][1] * m[2][3] - m[2][1] * m[1][3];
+  float c08 = m[2][1] * m[3][2] - m[3][1] * m[2][2], c10 = m[1][1] * m[3][2] - m[3][1] * m[1][2];
+  float c11 = m[1][1] * m[2][2] - m[2][1] * m[1][2], c12 = m[2][0] * m[3][3] - m[3][0] * m[2][3];
+  float c14 = m[1][0] * m[3][3] - m[3][0] * m[1][3], c15 = m[1][0] * m[2][3] - m[2][0] * m[1][3];
+  float c16 = m[2][0] * m[3][2] - m[3][0] * m[2][2], c18 = m[1][0] * m[3][2] - m[3][0] * m[1][2];
+  float c19 = m[1][0] * m[2][2] - m[2][0] * m[1][2], c20 = m[2][0] * m[3][1] - m[3][0] * m[2][1];
+  float c22 = m[1][0] * m[3][1] - m[3][0] * m[1][1], c23 = m[1][0] * m[2][1] - m[2][0] * m[1][1];
+  const float f0[4] = {c00, c00, c02, c03}, f1[4] = {c04, c04, c06, c07}, f2[4] = {c08, c08, c10, c11};
+  const float f3[4] = {c12, c12, c14, c15}, f4[4] = {c16, c16, c18, c19}, f5[4] = {c20, c20, c22, c23};
+  const float v0[4] = {m[1][0], m[0][0], m[0][0], m[0][0]}, v1[4] = {m[1][1], m[0][1], m[0][1], m[0][1]};
+  const float v2[4] = {m[1][2], m[0][2], m[0][2], m[0][2]}, v3[4] = {m[1][3], m[0][3], m[0][3], m[0][3]};
+  mat4 inv;
+  for (int k = 0; k < 4; k++) {
+    const float sa = (k & 1) ? -1.0f : 1.0f, sb = -sa;
+    inv.c[0][k] = ((v1[k] * f0[k] - v2[k] * f1[k]) + v3[k] * f2[k]) * sa;
+    inv.c[1][k] = ((v0[k] * f0[k] - v2[k] * f3[k]) + v3[k] * f4[k]) * sb;
+    inv.c[2][k] = ((v0[k] * f1[k] - v1[k] * f3[k]) + v3[k] * f5[k]) * sa;
+    inv.c[3][k] = ((v0[k] * f2[k] - v1[k] * f4[k]) + v2[k] * f5[k]) * sb;
+  }
+  const float d0 = m[0][0] * inv.c[0][0], d1 = m[0][1] * inv.c[1][0], d2 = m[0][2] * inv.c[2][0], d3 = m[0][3] * inv.c[3][0];
+  const float one_over_det = 1.0f / ((d0 + d1) + (d2 + d3));
   for (int c = 0; c < 4; c++)
-    for (int r = 0; r < 4; r++) a[r][c] = M.c[c][r];
-  auto det3 = [](float m00, float m01, float m02, float m10, float m11, float m12, float m20, float m21, float m22) {
-    return (m00 * (m11 * m22 - m12 * m21) - m01 * (m10 * m22 - m12 * m20)) + m02 * (m10 * m21 - m11 * m20);
-  };
-  float cof[4][4];
-  for (int r = 0; r < 4; r++)
-    for (int c = 0; c < 4; c++) {
-      float m[3][3];
-      int rr = 0;
-      for (int i = 0; i < 4; i++) {
-        if (i == r) continue;
-        int cc = 0;
-        for (int j = 0; j < 4; j++) {
-          if (j == c) continue;
-          m[rr][cc++] = a[i][j];
-        }
-        rr++;
-      }
-      float d = det3(m[0][0], m[0][1], m[0][2], m[1][0], m[1][1], m[1][2], m[2][0], m[2][1], m[2][2]);
-      cof[r][c] = ((r + c) & 1) ? -d : d;
-    }
-  float det = ((a[0][0] * cof[0][0] + a[0][1] * cof[0][1]) + a[0][2] * cof[0][2]) + a[0][3] * cof[0][3];
-  float inv = 1.0f / det;
-  mat4 o;
-  for (int r = 0; r < 4; r++)
-    for (int c = 0; c < 4; c++) o.c[c][r] = cof[c][r] * inv; // inverse = adjugate^T / det
-  return o;
+    for (int r = 0; r < 4; r++) inv.c[c][r] *= one_over_det;
+  return inv;
 }
 
 Material disneyDefaults() {
@@ -314,6 +314,10 @@ void readObj(const std::string& filepath, std::vector<Triangle>& triangles, Mate
 // same permutation; triangles are physically permuted once at the end.  Bounds
 // and centroids are pure functions of a triangle and are computed once.
 
+static thread_local TieOrder g_tie_order = TieOrder::Stable;
+void setTieOrder(TieOrder t) { g_tie_order = t; }
+TieOrder tieOrder() { return g_tie_order; }
+
 BVHNode testNode() { // P3/main.cpp:707-713 (index is left uninitialised there; 0 here)
   BVHNode n;
   n.left = 255;
@@ -371,9 +375,11 @@ struct Builder {
       int s = order[(size_t)(l - l0 + i)];
       recs[(size_t)i] = SortRec{aux[(size_t)s].cen[axis], s};
     }
-    // std::sort leaves the order of equal keys to the library (parity unpinned); here equal
+    // std::sort leaves the order of equal keys to the library (parity unpinned); by default equal
     // keys keep their current order, which is what the numpy restatement and the GPU builder do too
-    std::stable_sort(recs.begin(), recs.end(), [](const SortRec& a, const SortRec& b) { return a.key < b.key; });
+    auto cmp = [](const SortRec& a, const SortRec& b) { return a.key < b.key; };
+    if (g_tie_order == TieOrder::LibrarySort) std::sort(recs.begin(), recs.end(), cmp);
+    else std::stable_sort(recs.begin(), recs.end(), cmp);
     for (int i = 0; i < n; i++) order[(size_t)(l - l0 + i)] = recs[(size_t)i].slot;
     stats.sorts++;
   }

@@ -67,6 +67,13 @@ def getTransformMatrix(rotateCtrl, translateCtrl, scaleCtrl):
     return out
 
 
+def setTieOrder(library_sort):
+    """False (default): equal centroid keys keep their order (stable; == the GPU builder).  True: this
+    toolchain's std::sort, i.e. the permutation the reference's std::sort produces when built here."""
+    lib = _abi.load_host()
+    _check(lib.ezrt_host_set_tie_order(int(bool(library_sort))), lib)
+
+
 class HostScene:
     """std::vector<Triangle> + std::vector<BVHNode> of a reference main()."""
 

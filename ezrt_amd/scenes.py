@@ -2,11 +2,13 @@
 the host scene-build API exactly as the reference's main() would:
 readObj x N -> nodes = {testNode} -> buildBVHwithSAH(.., 8) -> encode.
 
-Geometry comes from tests/golden/meshes.npz (raw OBJ vertices/faces extracted
+Geometry comes from ezrt_amd/assets/meshes.npz (raw OBJ vertices/faces extracted
 from the reference's model files by tests/golden/make_fixtures.py) turned back
-into OBJ text, so readObj's parsing + normalisation path is exercised.  The env
-map is procedural (`synthetic_hdr`): the reference's HDR assets are absent or
-must not be read at run time on the GPU box.
+into OBJ text, so readObj's parsing + normalisation path is exercised.  Env maps:
+`shipped_hdr()` = the RGBE texels of the only HDR the reference ships
+(P4/HDR/peppermint_powerplant_4k.hdr, SURVEY-C2's env; a data asset under
+ezrt_amd/assets/, decoded with HDRLoader's formula), or the procedural
+`synthetic_hdr` (no asset needed).  /root/reference is never read at run time.
 """
 import os
 
@@ -17,7 +19,9 @@ from ._abi import (FILTER_BILINEAR, FILTER_NEAREST, INTEGRATOR_P3_DIFFUSE, INTEG
                    INTEGRATOR_P5_MIS, INTEGRATOR_P5_SOBOL)
 
 _REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-MESHES = os.path.join(_REPO, "tests", "golden", "meshes.npz")
+ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+MESHES = os.path.join(ASSETS, "meshes.npz")
+SHIPPED_HDR = os.path.join(ASSETS, "env_peppermint_powerplant_1024x512_rgbe.npz")
 
 _mesh_cache = {}
 
@@ -61,6 +65,34 @@ def subdivide(v, f, levels=1):
             np.stack([m20, m12, f[:, 2]], 1),
             np.stack([m01, m12, m20], 1)], axis=0)
     return v, f.astype(np.int32)
+
+
+_shipped_hdr_cache = {}
+
+
+def shipped_hdr():
+    """float32 [512, 1024, 3], row 0 = top scanline: the reference's only shipped env map
+    (P4/HDR/peppermint_powerplant_4k.hdr) from its RGBE texels, converted as HDRLoader does
+    (lib/hdrloader.cpp:97-114: component / 256 * 2^(E - 128), exact in fp32).  Bit-identical to the
+    reference loader's output on the file (tests/test_ref_pin.py, tests/golden/hdr_probe.json)."""
+    if "a" not in _shipped_hdr_cache:
+        with np.load(SHIPPED_HDR) as z:
+            rgbe = z["rgbe"]
+        v = rgbe[..., :3].astype(np.float32) / np.float32(256.0)
+        d = np.ldexp(np.float32(1.0), rgbe[..., 3].astype(np.int32) - 128).astype(np.float32)
+        _shipped_hdr_cache["a"] = np.ascontiguousarray(v * d[..., None], np.float32)
+    return _shipped_hdr_cache["a"]
+
+
+def env_map(name):
+    """"shipped" | "synthetic" | an array | None -> float32 [h, w, 3] or None"""
+    if isinstance(name, str):
+        if name == "shipped":
+            return shipped_hdr()
+        if name == "synthetic":
+            return synthetic_hdr()
+        raise ValueError("unknown env map %r" % name)
+    return name
 
 
 def _hash_u32(x):
@@ -160,7 +192,7 @@ def bunny_scene(subdiv=0, materials="p4", hdr="synthetic", want_cache=False, env
     sv, sf = mesh("sphere")
     hs.readObjText(obj_text(sv, sf), mk(baseColor=(1, 1, 1), emissive=(30, 20, 10)),
                    S.getTransformMatrix((0, 0, 0), (0.0, 0.9, -0.0), (1, 1, 1)), False)
-    h = synthetic_hdr() if isinstance(hdr, str) and hdr == "synthetic" else hdr
+    h = env_map(hdr)
     return _finish("bunny_sub%d" % subdiv, hs, leaf_n, h, want_cache, env_filter, sah)
 
 
@@ -178,7 +210,7 @@ def p5_scene(subdiv=0, hdr="synthetic", leaf_n=8):
                           baseColor=(1, 1, 1))
     qv, qf = mesh("quad")
     hs.readObjText(obj_text(qv, qf), m, S.getTransformMatrix((0, 0, 0), (0, -0.5, 0), (13000.0, 0.01, 13000.0)), False)
-    h = synthetic_hdr() if isinstance(hdr, str) and hdr == "synthetic" else hdr
+    h = env_map(hdr)
     return _finish("p5_sub%d" % subdiv, hs, leaf_n, h, True, FILTER_BILINEAR)
 
 
@@ -272,7 +304,7 @@ def mega_scene(hdr="synthetic", leaf_n=8, gpu_build=None):
     for k, (x, z) in enumerate(((-4.0, -2.0), (4.0, -2.0), (-4.0, 3.0), (4.0, 3.0))):
         m = S.Material.disney(baseColor=(1, 1, 1), emissive=(18.0, 16.0 - 2.0 * k, 10.0 + 2.0 * k))
         hs.readObjText(quad, m, S.getTransformMatrix((180, 0, 0), (x, 3.2, z), (1.5, 1.0, 1.5)), False)
-    h = synthetic_hdr() if isinstance(hdr, str) and hdr == "synthetic" else hdr
+    h = env_map(hdr)
     return _finish("mega_1m", hs, leaf_n, h, True, FILTER_BILINEAR, gpu_build=gpu_build)
 
 
@@ -300,5 +332,5 @@ def disney_grid_scene(subdiv=3, hdr="synthetic", leaf_n=8):
     qv, qf = mesh("quad")
     hs.readObjText(obj_text(qv, qf), S.Material.disney(baseColor=(0.725, 0.71, 0.68)),
                    S.getTransformMatrix((0, 0, 0), (0, -1.4, 0), (18.83, 0.01, 18.83)), False)
-    h = synthetic_hdr() if isinstance(hdr, str) and hdr == "synthetic" else hdr
+    h = env_map(hdr)
     return _finish("disney_grid_sub%d" % subdiv, hs, leaf_n, h, False, FILTER_NEAREST)

@@ -159,11 +159,14 @@ class TraceLib:
             raise TraceError(self.lib.ezrt_last_error().decode())
         return out
 
-    def debug_math(self, op, a, b=None):
+    def debug_math(self, op, a, b=None, n=None):
+        """ops 0-9: elementwise det-math; ops 10-12 (intersector audit): a = [n,6] rays,
+        b = [n,6] boxes (10 hitAABB, 12 its v_min3/v_max3 form) or [n,9] triangles (11 hitTriangle)."""
         a = np.ascontiguousarray(a, np.float32)
         bb = np.ascontiguousarray(b, np.float32) if b is not None else np.zeros_like(a)
-        out = np.zeros_like(a)
-        rc = self.lib.ezrt_debug_math(int(op), _fp(a), _fp(bb), a.size, _fp(out))
+        n = a.size if n is None else int(n)
+        out = np.zeros(n, np.float32) if op >= 10 else np.zeros_like(a)
+        rc = self.lib.ezrt_debug_math(int(op), _fp(a), _fp(bb), n, _fp(out))
         if rc != 0:
             raise TraceError(self.lib.ezrt_last_error().decode())
         return out

@@ -116,6 +116,19 @@ BVHNode testNode();
 int buildBVH(std::vector<Triangle>& triangles, std::vector<BVHNode>& nodes, int l, int r, int n);
 int buildBVHwithSAH(std::vector<Triangle>& triangles, std::vector<BVHNode>& nodes, int l, int r, int n);
 
+// Order of triangles whose sort keys (centroid coordinates) are exactly equal.  The reference calls
+// std::sort, which leaves it to the C++ library (parity unpinned):
+//   Stable     (default) equal keys keep their current order -- platform independent, and what the GPU
+//              builder (ezrt_build_sah, LSD radix sort) produces;
+//   LibrarySort  this toolchain's std::sort on the same keys and comparator: its control flow depends
+//              on comparison results only, so the permutation is the one the reference's std::sort of
+//              144-byte structs produces when built with the same library (checked against
+//              oracle/_ref = the reference compiled here, tests/test_ref_pin.py).
+// Per thread, like lastBuildStats().
+enum class TieOrder { Stable = 0, LibrarySort = 1 };
+void setTieOrder(TieOrder t);
+TieOrder tieOrder();
+
 // statistics of the last buildBVHwithSAH call on this thread
 struct BuildStats {
   int64_t inf_cap_nodes = 0; // inner nodes whose every SAH candidate cost >= INF (median-x fallback)

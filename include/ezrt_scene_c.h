@@ -39,6 +39,9 @@ int ezrt_host_add_triangles(EzrtHostScene* h, const float* tri36, int n);
 /* nodes = {testNode}; buildBVH / buildBVHwithSAH(triangles, nodes, 0, n-1, leaf_n)
  * (P3/main.cpp:707-715).  method: 0 = median (buildBVH), 1 = SAH. */
 int ezrt_host_build_bvh(EzrtHostScene* h, int method, int leaf_n);
+/* order of triangles with exactly equal sort keys (per calling thread): 0 = stable (default),
+ * 1 = this toolchain's std::sort = what the reference's std::sort does when built here */
+int ezrt_host_set_tie_order(int library_sort);
 /* [0] inf-cap fallback nodes [1] std::sort calls [2] max depth (root = 1) */
 int ezrt_host_build_stats(EzrtHostScene* h, int64_t out[3]);
 

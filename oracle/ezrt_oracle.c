@@ -1068,6 +1068,32 @@ int ezrt_scene_stats(EzrtScene* s, int64_t out[6]) {
 
 int ezrt_debug_math(int op, const float* a, const float* b, int n, float* out) {
   if (!a || !out || n < 0) return fail(EZRT_ERR_INVALID, "NULL argument");
+  if (op == 10 || op == 12) { /* hitAABB: a = n rays (S, d), b = n boxes (AA, BB) */
+    if (!b) return fail(EZRT_ERR_INVALID, "NULL argument");
+    for (int i = 0; i < n; i++) {
+      const float *r = a + 6 * (size_t)i, *q = b + 6 * (size_t)i;
+      out[i] = hit_aabb(V3(r[0], r[1], r[2]), V3(r[3], r[4], r[5]), V3(q[0], q[1], q[2]), V3(q[3], q[4], q[5]));
+    }
+    return 0;
+  }
+  if (op == 11) { /* hitTriangle: a = n rays, b = n triangles (p1 p2 p3); out = t, INF on a miss */
+    if (!b) return fail(EZRT_ERR_INVALID, "NULL argument");
+    for (int i = 0; i < n; i++) {
+      float rec[36];
+      memset(rec, 0, sizeof rec);
+      memcpy(rec, b + 9 * (size_t)i, 9 * sizeof(float));
+      struct EzrtScene tmp;
+      memset(&tmp, 0, sizeof tmp);
+      tmp.tri = rec;
+      Ctr ctr;
+      memset(&ctr, 0, sizeof ctr);
+      Ctx cx = {&tmp, &ctr, 0, 1};
+      const float* r = a + 6 * (size_t)i;
+      HitResult h = hit_triangle(&cx, 0, V3(r[0], r[1], r[2]), V3(r[3], r[4], r[5]));
+      out[i] = h.isHit ? h.distance : INF;
+    }
+    return 0;
+  }
   for (int i = 0; i < n; i++) {
     float x = a[i], y = b ? b[i] : 0.0f, r;
     switch (op) {

@@ -204,15 +204,43 @@ def test_hdr_loader_decodes_rle_and_flat_files():
         S.hdrLoad(data=b"not a radiance file at all")
 
 
-@pytest.mark.skipif(not os.path.exists(P4_HDR), reason="reference not mounted")
-def test_hdr_loader_on_the_shipped_hdr_matches_committed_probe():
+def _bits_sum(a):
+    return int(np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64).sum())
+
+
+def test_shipped_hdr_asset_and_its_cache_match_the_reference_produced_probes():
+    """tests/golden/hdr_probe.json holds texels + checksums of P4/HDR/peppermint_powerplant_4k.hdr as
+    decoded by the REFERENCE's HDRLoader::load and of the REFERENCE's calculateHdrCache on it (made by
+    tests/golden/make_fixtures.py through oracle/_ref).  The asset copy and our cache must reproduce them."""
     import json
     info = json.load(open(os.path.join(ROOT, "tests", "golden", "hdr_probe.json")))
-    hdr = S.hdrLoad(P4_HDR)
+    assert "oracle/_ref" in info["produced_by"]
+    hdr = scenes.shipped_hdr()
     assert hdr.shape == (info["height"], info["width"], 3) == (512, 1024, 3)
+    cache = S.calculateHdrCache(hdr)
     for pr in info["probes"]:
         assert [int(x) for x in hdr[pr["row"], pr["col"]].view(np.uint32)] == pr["rgb_bits"]
+        assert [int(x) for x in cache[pr["row"], pr["col"]].view(np.uint32)] == pr["cache_bits"]
     assert int(np.bitwise_xor.reduce(hdr.view(np.uint32).ravel())) == info["xor_bits"]
+    assert _bits_sum(hdr) == info["sum_bits"]
+    assert int(np.bitwise_xor.reduce(cache.view(np.uint32).ravel())) == info["cache_xor_bits"]
+    assert _bits_sum(cache) == info["cache_sum_bits"]
+    if os.path.exists(P4_HDR):                      # our loader on the file itself
+        assert np.array_equal(S.hdrLoad(P4_HDR).view(np.uint32), hdr.view(np.uint32))
+
+
+def test_canned_p3_scene_matches_the_reference_main_checksums():
+    """tests/golden/ref_scene_p3.json = what chapter 3's main() uploads (run headless through
+    oracle/_ref): the canned scene rebuilt from the mesh assets gives the same two arrays."""
+    import json
+    info = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_scene_p3.json")))
+    b = scenes.bunny_scene(subdiv=0, materials="p3", hdr=None)
+    assert b.tri.shape[0] == info["nTriangles"] and b.nodes.shape[0] == info["nNodes"]
+    assert int(np.bitwise_xor.reduce(b.tri.view(np.uint32).ravel())) == info["tri_xor_bits"]
+    assert _bits_sum(b.tri) == info["tri_sum_bits"]
+    assert int(np.bitwise_xor.reduce(b.nodes.view(np.uint32).ravel())) == info["nodes_xor_bits"]
+    assert _bits_sum(b.nodes) == info["nodes_sum_bits"]
+    assert b.nodes[1].tolist() == info["node1"] and b.tri[0].tolist() == info["tri0"]
 
 
 def test_hdr_cache_matches_numpy_restatement():
