@@ -80,22 +80,43 @@ struct Tuning {
   int rel_boxes = 1;       // primary rays traverse boxes already translated by the eye
   int steal = 1;           // intra-wave work stealing in traceq_kernel (+ a redo launch for exact ties)
   int debug_stages = 0;    // print per-stage queue sizes (synchronises)
+  int audit_via_queue = 0; // 1: ezrt_query_hits and ezrt_render_paths run through the TIMED kernels (traceq_kernel with
+                           // the template, LDS layout, stealing and redo launch of a render call + the streaming shading
+                           // stages) instead of the in-order audit kernels; 2 (query only): additionally treat the rays as
+                           // sharing ray 0's origin, i.e. the primary stage's const_origin / pre-translated-box variant
 };
 struct TuningName {
   const char* name;
   int Tuning::*field;
+  int lo, hi; // accepted range (ezrt_set_option rejects anything else; environment overrides are clamped)
 };
-const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel}, {"packet", &Tuning::packet},
-                              {"packet_budget", &Tuning::packet_budget}, {"leaf_threshold", &Tuning::leaf_threshold},
-                              {"pool_div", &Tuning::pool_div}, {"pool_max", &Tuning::pool_max},
-                              {"trace_wps", &Tuning::trace_wps}, {"lds_nodes", &Tuning::lds_nodes},
-                              {"steal", &Tuning::steal}, {"rel_boxes", &Tuning::rel_boxes}, {"split_shade", &Tuning::split_shade}, {"refill_min", &Tuning::refill_min}, {"static_pct", &Tuning::static_pct}, {"pipes", &Tuning::pipes}, {"sub_frames", &Tuning::sub_frames}, {"scatter", &Tuning::scatter}, {"debug_stages", &Tuning::debug_stages}};
+const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
+                              {"packet", &Tuning::packet, 0, 1},
+                              {"packet_budget", &Tuning::packet_budget, 1, 1 << 20},
+                              {"leaf_threshold", &Tuning::leaf_threshold, 1, 64},
+                              {"pool_div", &Tuning::pool_div, 1, 1 << 16},
+                              {"pool_max", &Tuning::pool_max, 8, 4096},
+                              {"trace_wps", &Tuning::trace_wps, 1, 8},
+                              {"lds_nodes", &Tuning::lds_nodes, 0, 1 << 24},
+                              {"steal", &Tuning::steal, 0, 1},
+                              {"rel_boxes", &Tuning::rel_boxes, 0, 1},
+                              {"split_shade", &Tuning::split_shade, 0, 2},
+                              {"refill_min", &Tuning::refill_min, 1, 64},
+                              {"static_pct", &Tuning::static_pct, 0, 95},
+                              {"pipes", &Tuning::pipes, 1, 2},
+                              {"sub_frames", &Tuning::sub_frames, 0, 1 << 20},
+                              {"scatter", &Tuning::scatter, 0, 8},
+                              {"debug_stages", &Tuning::debug_stages, 0, 2},
+                              {"audit_via_queue", &Tuning::audit_via_queue, 0, 2}};
 Tuning tuning_from_env() {
   Tuning t;
   for (const TuningName& k : kTuning) {
     std::string env = "EZRT_";
     for (const char* c = k.name; *c; c++) env += (char)((*c >= 'a' && *c <= 'z') ? (*c - 32) : *c);
-    if (const char* e = getenv(env.c_str())) t.*(k.field) = atoi(e);
+    if (const char* e = getenv(env.c_str())) {
+      int v = atoi(e);
+      t.*(k.field) = v < k.lo ? k.lo : (v > k.hi ? k.hi : v);
+    }
   }
   return t;
 }
@@ -281,6 +302,69 @@ size_t stack_lds_bytes(const EzrtScene* s) {
 }
 
 
+
+// Launch configuration of traceq_kernel (shared by the render pipeline and the audit routes).
+// LDS per workgroup: traversal stack + lane table + as many top-of-tree records (80 B each) as fit
+// when the register budget's `trace_wps` waves/SIMD (= trace_wps workgroups of 256 per CU) are resident
+struct TraceCfg {
+  size_t lds = 0, lds_t = 0;
+  int lds_nodes = 0, blocks_per_cu = 1;
+  unsigned grid_full = 0;
+};
+int ensure_num_cus(EzrtScene* s) {
+  if (!s->num_cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    s->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return 0;
+}
+TraceCfg trace_cfg(const EzrtScene* s) { // needs s->num_cus
+  TraceCfg c;
+  const Tuning& tu = s->tune;
+  c.lds = stack_lds_bytes(s);
+  const size_t lds_fixed = c.lds + BLOCK * sizeof(int);
+  int blocks_per_cu = tu.trace_wps > 0 ? tu.trace_wps : 5;
+  if ((size_t)blocks_per_cu * lds_fixed > 158 * 1024) blocks_per_cu = (int)((158 * 1024) / lds_fixed);
+  if (blocks_per_cu < 1) blocks_per_cu = 1;
+  size_t lds_budget = (size_t)(158 * 1024) / blocks_per_cu;
+  if (lds_budget > 64 * 1024) lds_budget = 64 * 1024; // static cap of a dynamic-LDS launch without opt-in
+  lds_budget -= lds_budget / 16; // allocation-granule slack: a workgroup must not lose its CU slot to rounding
+  int lds_nodes = lds_budget > lds_fixed ? (int)((lds_budget - lds_fixed) / 80) : 0;
+  if (lds_nodes > s->n_inner) lds_nodes = s->n_inner;
+  if (lds_nodes > tu.lds_nodes) lds_nodes = tu.lds_nodes;
+  if (lds_nodes < 0) lds_nodes = 0;
+  c.lds_nodes = lds_nodes;
+  c.lds_t = lds_fixed + (size_t)lds_nodes * 80;
+  c.blocks_per_cu = blocks_per_cu;
+  c.grid_full = (unsigned)(s->num_cus * blocks_per_cu);
+  return c;
+}
+// the template instance a render call uses for this scene's settings
+void launch_traceq_cfg(EzrtScene* s, const TraceCfg& c, const TraceQArgs& q, bool small, hipStream_t st) {
+  const unsigned trace_grid = small ? 64u : c.grid_full; // redo lists are (nearly) empty
+  const int trace_wps = s->tune.trace_wps;
+  if (s->instr > 0) hipLaunchKernelGGL((traceq_kernel<true, 6>), dim3(trace_grid), dim3(BLOCK), c.lds_t, st, q);
+  else if (trace_wps == 8) hipLaunchKernelGGL((traceq_kernel<false, 8>), dim3(trace_grid), dim3(BLOCK), c.lds_t, st, q);
+  else if (trace_wps == 6) hipLaunchKernelGGL((traceq_kernel<false, 6>), dim3(trace_grid), dim3(BLOCK), c.lds_t, st, q);
+  else if (trace_wps == 4) hipLaunchKernelGGL((traceq_kernel<false, 4>), dim3(trace_grid), dim3(BLOCK), c.lds_t, st, q);
+  else hipLaunchKernelGGL((traceq_kernel<false, 5>), dim3(trace_grid), dim3(BLOCK), c.lds_t, st, q);
+  s->n_trace_launches++;
+}
+// schedule fields of a traceq launch that come from the knobs (clamped: ADVICE r1)
+void fill_trace_knobs(const EzrtScene* s, const TraceCfg& c, TraceQArgs& t) {
+  const Tuning& tu = s->tune;
+  t.leaf_threshold = tu.leaf_threshold < 1 ? 1 : (tu.leaf_threshold > 64 ? 64 : tu.leaf_threshold);
+  t.static_pct = (uint32_t)(tu.static_pct < 0 ? 0 : (tu.static_pct > 95 ? 95 : tu.static_pct));
+  t.refill_min = (uint32_t)(tu.refill_min < 1 ? 1 : (tu.refill_min > 64 ? 64 : tu.refill_min));
+  t.pool_div = (uint32_t)(tu.pool_div < 1 ? 1 : tu.pool_div);
+  t.pool_max = (uint32_t)(tu.pool_max < (int)TRACE_POOL_MIN ? (int)TRACE_POOL_MIN : (tu.pool_max > 4096 ? 4096 : tu.pool_max));
+  t.stack_entries = (int32_t)(c.lds / (BLOCK * sizeof(int)));
+  t.lds_nodes = c.lds_nodes;
+}
+
 // ---- wavefront pipeline for one chunk of frames (all launches asynchronous on `st`)
 template <int INTEG>
 void launch_shade_i(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
@@ -319,7 +403,13 @@ void launch_shade(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
   }
 }
 
-int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, uint32_t frame_first, uint32_t nf, hipStream_t st) {
+struct PathLogTarget { // ezrt_render_paths through the timed pipeline (audit_via_queue)
+  int32_t* tri = nullptr;
+  float* t = nullptr;
+  float* colour = nullptr;
+};
+int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, uint32_t frame_first, uint32_t nf, hipStream_t st,
+                    const PathLogTarget* plog = nullptr) {
   const bool mis = p->integrator == EZRT_INTEGRATOR_P5_MIS;
   const bool full = s->instr > 0;
   const size_t n_slots = (size_t)nb * BLOCK * nf;
@@ -346,12 +436,9 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
   HIP_TRY(hipMemsetAsync(pp.qcounts.p, 0, 320 * sizeof(uint32_t), st));
   HIP_TRY(pp.defer_list.ensure(n_slots + (size_t)2048 * 1024)); // per-workgroup regions: iterations x SHADE_BLOCK each
   HIP_TRY(pp.defer_count.ensure(2048u * 1024u / SHADE_BLOCK));
-  if (!s->num_cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipGetDeviceProperties(&prop, dev));
-    s->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  {
+    int rc_cu = ensure_num_cus(s);
+    if (rc_cu) return rc_cu;
   }
   auto queue = [&](int k) {
     RayQueue q;
@@ -416,25 +503,10 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
   }
   hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((n_slots + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, a);
 
-  const size_t lds = stack_lds_bytes(s);
   const Tuning& tu = s->tune;
-  const int trace_wps = tu.trace_wps, lds_nodes_max = tu.lds_nodes, use_packet = tu.packet,
-            packet_budget = tu.packet_budget, debug_stages = tu.debug_stages, pool_div = tu.pool_div,
-            pool_max = tu.pool_max, leaf_thr = tu.leaf_threshold;
-  // LDS per workgroup: traversal stack + lane table + as many top-of-tree records (80 B each) as fit
-  // when the register budget's `trace_wps` waves/SIMD (= trace_wps workgroups of 256 per CU) are resident
-  const size_t lds_fixed = lds + BLOCK * sizeof(int);
-  int blocks_per_cu = trace_wps > 0 ? trace_wps : 5;
-  if ((size_t)blocks_per_cu * lds_fixed > 158 * 1024) blocks_per_cu = (int)((158 * 1024) / lds_fixed);
-  if (blocks_per_cu < 1) blocks_per_cu = 1;
-  size_t lds_budget = (size_t)(158 * 1024) / blocks_per_cu;
-  if (lds_budget > 64 * 1024) lds_budget = 64 * 1024;
-  lds_budget -= lds_budget / 16; // allocation-granule slack: a workgroup must not lose its CU slot to rounding // static cap of a dynamic-LDS launch without opt-in
-  int lds_nodes = lds_budget > lds_fixed ? (int)((lds_budget - lds_fixed) / 80) : 0;
-  if (lds_nodes > s->n_inner) lds_nodes = s->n_inner;
-  if (lds_nodes > lds_nodes_max) lds_nodes = lds_nodes_max;
-  const size_t lds_t = lds_fixed + (size_t)lds_nodes * 80;
-  const unsigned trace_grid_full = (unsigned)(s->num_cus * blocks_per_cu);
+  const TraceCfg cfg = trace_cfg(s);
+  const int use_packet = tu.packet, packet_budget = tu.packet_budget, debug_stages = tu.debug_stages;
+  const unsigned trace_grid_full = cfg.grid_full;
   unsigned shade_grid = (unsigned)((n_slots + SHADE_BLOCK - 1) / SHADE_BLOCK);
   const unsigned shade_grid_max = 2048u * 1024u / SHADE_BLOCK; // 8 workgroup-iterations' worth of resident threads
   if (shade_grid > shade_grid_max) shade_grid = shade_grid_max;
@@ -454,13 +526,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     t.origin[2] = p->eye[2];
     t.head = pp.qheads.p + (size_t)b * HEAD_SLOT;
     t.counters = s->counters.p;
-    t.leaf_threshold = leaf_thr;
-    t.static_pct = (uint32_t)(tu.static_pct < 0 ? 0 : (tu.static_pct > 95 ? 95 : tu.static_pct));
-    t.refill_min = (uint32_t)(tu.refill_min < 1 ? 1 : (tu.refill_min > 64 ? 64 : tu.refill_min));
-    t.pool_div = (uint32_t)pool_div;
-    t.pool_max = (uint32_t)pool_max;
-    t.stack_entries = (int32_t)(lds / (BLOCK * sizeof(int)));
-    t.lds_nodes = lds_nodes;
+    fill_trace_knobs(s, cfg, t);
     t.dbg = debug_stages ? (pp.qcounts.p + 100 + 4 * (b & 3)) : nullptr;
     t.slot_map = nullptr;
     t.steal = tu.steal ? 1u : 0u;
@@ -474,15 +540,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
       HIP_TRY(hipMemsetAsync(pp.wave_log.p, 0, (size_t)trace_grid_full * (BLOCK / 64) * 8 * sizeof(unsigned long long), st));
       t.wave_log = pp.wave_log.p;
     }
-    auto launch_traceq = [&](const TraceQArgs& q, bool small = false) {
-      const unsigned trace_grid = small ? 64u : trace_grid_full; // redo lists are (nearly) empty
-      if (full) hipLaunchKernelGGL((traceq_kernel<true, 6>), dim3(trace_grid), dim3(BLOCK), lds_t, st, q);
-      else if (trace_wps == 8) hipLaunchKernelGGL((traceq_kernel<false, 8>), dim3(trace_grid), dim3(BLOCK), lds_t, st, q);
-      else if (trace_wps == 6) hipLaunchKernelGGL((traceq_kernel<false, 6>), dim3(trace_grid), dim3(BLOCK), lds_t, st, q);
-      else if (trace_wps == 4) hipLaunchKernelGGL((traceq_kernel<false, 4>), dim3(trace_grid), dim3(BLOCK), lds_t, st, q);
-      else hipLaunchKernelGGL((traceq_kernel<false, 5>), dim3(trace_grid), dim3(BLOCK), lds_t, st, q);
-      s->n_trace_launches++;
-    };
+    auto launch_traceq = [&](const TraceQArgs& q, bool small = false) { launch_traceq_cfg(s, cfg, q, small, st); };
     int e = s->n_trace_events;
     if (e < MAX_TRACE_EVENTS) HIP_TRY(hipEventRecord(s->ev_trace[e][0], st));
     if (b == 0 && !full && use_packet) {
@@ -534,6 +592,28 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     if (e < MAX_TRACE_EVENTS) {
       HIP_TRY(hipEventRecord(s->ev_trace[e][1], st));
       s->n_trace_events++;
+    }
+    if (plog) { // audit: this stage's hit records, exactly as the trace (+ redo) launches left them
+      PathLogArgs g;
+      g.hits = pp.hits2[in].p;
+      g.rq_d = queue(in).d;
+      g.st_s2 = state(in).s2;
+      g.n_in = pp.qcounts.p + b;
+      g.n_slots = (uint32_t)n_slots;
+      g.bounce = b;
+      g.mis = mis ? 1 : 0;
+      g.blocks = s->blocks.p;
+      g.n_blocks = nb;
+      g.frame_first = frame_first;
+      g.scatter = a.scatter;
+      g.scatter_shift = a.scatter_shift;
+      g.width = p->width;
+      g.log_slots = 1 + 2 * p->max_bounce;
+      g.log_tri = plog->tri;
+      g.log_t = plog->t;
+      g.log_colour = plog->colour;
+      g.samples = pp.samples.p;
+      hipLaunchKernelGGL(pathlog_kernel, dim3((unsigned)((n_slots + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, g);
     }
     a.hits = pp.hits2[in].p;
     a.hits_out = reinterpret_cast<unsigned long long*>(pp.hits2[out].p);
@@ -609,6 +689,17 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
       fprintf(stderr, "[ezrt] stage %d: paths_in %u paths_out %u | cum rays %llu pops %llu inner %llu tris %llu | max/ray pops %u tris %u iters %u\n", b, q[0],
               q[1], c[0], c[1], c[2], c[3], dbg[0], dbg[1], dbg[2]);
     }
+  }
+  if (plog && plog->colour) {
+    PathLogArgs g;
+    memset(&g, 0, sizeof g);
+    g.blocks = s->blocks.p;
+    g.n_blocks = nb;
+    g.frame_first = frame_first;
+    g.width = p->width;
+    g.log_colour = plog->colour;
+    g.samples = pp.samples.p;
+    hipLaunchKernelGGL(pathcolour_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, st, g, *p);
   }
   return 0;
 }
@@ -913,7 +1004,23 @@ int ezrt_render_paths(EzrtScene* s, const EzrtRenderParams* p, int32_t* tri_id, 
   HIP_TRY(hipMemcpy(dtri.p, tri_id, npix * slots * sizeof(int32_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(dt.p, t_hit, npix * slots * sizeof(float), hipMemcpyHostToDevice));
   if (colour) HIP_TRY(hipMemcpy(dcol.p, colour, npix * 3 * sizeof(float), hipMemcpyHostToDevice));
-  if (nb > 0) {
+  if (nb > 0 && s->tune.audit_via_queue) {
+    // the timed pipeline (raygen -> traceq_kernel + redo -> shading stages), one frame, hit records logged per stage
+    rc = ensure_events(s);
+    if (rc) return rc;
+    s->timed = false;
+    s->n_trace_events = 0;
+    s->n_trace_launches = 0;
+    Pipe& q = s->pipe[0];
+    HIP_TRY(q.samples.ensure((size_t)nb * BLOCK));
+    PathLogTarget tgt;
+    tgt.tri = dtri.p;
+    tgt.t = dt.p;
+    tgt.colour = colour ? dcol.p : nullptr;
+    rc = wavefront_chunk(s, q, p, nb, p->frame0, 1u, nullptr, &tgt);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+  } else if (nb > 0) {
     TraceArgs a;
     a.sc = s->dev();
     a.p = *p;
@@ -945,6 +1052,75 @@ int ezrt_query_hits(EzrtScene* s, const float* rays, int n_rays, int32_t* tri_id
   HIP_TRY(dt.ensure((size_t)n_rays));
   HIP_TRY(dtri.ensure((size_t)n_rays));
   HIP_TRY(hipMemcpy(dr.p, rays, (size_t)n_rays * 6 * sizeof(float), hipMemcpyHostToDevice));
+  if (s->tune.audit_via_queue) {
+    // the rays as ONE stage of a render call: same kernel template, LDS layout, pools, stealing, redo launch
+    int rc = ensure_num_cus(s);
+    if (rc) return rc;
+    Pipe& pp = s->pipe[0];
+    const size_t n = (size_t)n_rays;
+    constexpr size_t HEAD_SLOT = (size_t)TRACE_HEADS * TRACE_HEAD_STRIDE;
+    HIP_TRY(pp.rq_o[0].ensure(n));
+    HIP_TRY(pp.rq_d[0].ensure(n));
+    HIP_TRY(pp.hits2[0].ensure(n));
+    HIP_TRY(pp.redo_slots.ensure(n));
+    if (pp.redo_flag.n < n) {
+      HIP_TRY(pp.redo_flag.ensure(n));
+      HIP_TRY(hipMemset(pp.redo_flag.p, 0, pp.redo_flag.n * sizeof(uint32_t)));
+    }
+    HIP_TRY(pp.qheads.ensure(81 * HEAD_SLOT));
+    HIP_TRY(hipMemset(pp.qheads.p, 0, 81 * HEAD_SLOT * sizeof(uint32_t)));
+    HIP_TRY(pp.qcounts.ensure(320));
+    HIP_TRY(hipMemset(pp.qcounts.p, 0, 320 * sizeof(uint32_t)));
+    const unsigned g1 = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(query_pack_kernel, dim3(g1), dim3(256), 0, nullptr, dr.p, (uint32_t)n, pp.rq_o[0].p, pp.rq_d[0].p, pp.qcounts.p);
+    const TraceCfg cfg = trace_cfg(s);
+    const bool shared_origin = s->tune.audit_via_queue >= 2;
+    TraceQArgs t;
+    t.sc = s->dev();
+    t.rq.o = pp.rq_o[0].p;
+    t.rq.d = pp.rq_d[0].p;
+    t.hits = pp.hits2[0].p;
+    t.n_paths = pp.qcounts.p;
+    t.rays_per_path = 1u;
+    t.const_origin = shared_origin ? 1u : 0u;
+    t.inner_rel = nullptr;
+    t.origin[0] = rays[0];
+    t.origin[1] = rays[1];
+    t.origin[2] = rays[2];
+    if (shared_origin && s->tune.rel_boxes && s->n_inner > 0) {
+      HIP_TRY(pp.inner_rel.ensure((size_t)s->n_inner * 4));
+      hipLaunchKernelGGL(inner_rel_kernel, dim3((unsigned)((s->n_inner + 255) / 256)), dim3(256), 0, nullptr, s->inner.p, s->n_inner,
+                         rays[0], rays[1], rays[2], pp.inner_rel.p);
+      t.inner_rel = pp.inner_rel.p;
+    }
+    t.head = pp.qheads.p;
+    t.counters = s->counters.p;
+    fill_trace_knobs(s, cfg, t);
+    t.dbg = nullptr;
+    t.slot_map = nullptr;
+    t.steal = s->tune.steal ? 1u : 0u;
+    t.count_rays = 1u;
+    t.redo_count = pp.qcounts.p + 128;
+    t.redo_slots = pp.redo_slots.p;
+    t.redo_flag = pp.redo_flag.p;
+    t.wave_log = nullptr;
+    launch_traceq_cfg(s, cfg, t, false, nullptr);
+    if (t.steal) {
+      TraceQArgs r = t;
+      r.steal = 0u;
+      r.count_rays = 0u;
+      r.slot_map = pp.redo_slots.p;
+      r.n_paths = pp.qcounts.p + 128;
+      r.head = pp.qheads.p + (size_t)40 * HEAD_SLOT;
+      launch_traceq_cfg(s, cfg, r, true, nullptr);
+    }
+    hipLaunchKernelGGL(query_unpack_kernel, dim3(g1), dim3(256), 0, nullptr, pp.hits2[0].p, (uint32_t)n, dtri.p, dt.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(tri_id, dtri.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(t_hit, dt.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+  }
   QueryArgs a;
   a.sc = s->dev();
   a.rays = dr.p;
@@ -993,6 +1169,8 @@ int ezrt_set_option(EzrtScene* s, const char* name, int value) {
   if (!s || !name) return fail(EZRT_ERR_INVALID, "NULL argument");
   for (const TuningName& k : kTuning)
     if (strcmp(k.name, name) == 0) {
+      if (value < k.lo || value > k.hi)
+        return fail(EZRT_ERR_INVALID, "option '%s' = %d outside [%d, %d]", name, value, k.lo, k.hi);
       s->tune.*(k.field) = value;
       return 0;
     }

@@ -570,4 +570,87 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_kernel(WfArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Audit of the TIMED kernels (audit_via_queue): what traceq_kernel left in the hit records of one
+// stage, written to ezrt_render_paths' per-pixel log (slot 0 = primary; bounce i: 1 + 2i = env shadow
+// ray, 2 + 2i = bounce ray; -2 = ray not shot), and the chunk's sample radiance per pixel.
+struct PathLogArgs {
+  const int2* hits;      // hit records of the stage's ray queue
+  const float4* rq_d;    // its ray directions (.w = 0: slot not shot)
+  const float4* st_s2;   // path state of the queue (.w = bits(sample slot)); unused for stage 0
+  const uint32_t* n_in;  // paths in the queue (stage >= 1)
+  uint32_t n_slots;      // stage 0: pixel-samples of the chunk
+  int32_t bounce;        // stage index b (0 = primary rays)
+  int32_t mis;           // 1: two rays per path (2i = shadow, 2i + 1 = bounce)
+  const int2* blocks;
+  int32_t n_blocks;
+  uint32_t frame_first;
+  uint32_t scatter, scatter_shift;
+  int32_t width, log_slots;
+  int32_t* log_tri;
+  float* log_t;
+  float* log_colour;     // pathcolour_kernel
+  const float4* samples;
+};
+__global__ __launch_bounds__(BLOCK) void pathlog_kernel(PathLogArgs a) {
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  const uint32_t n = a.bounce == 0 ? a.n_slots : *a.n_in;
+  if (i >= n) return;
+  const uint32_t sslot = a.bounce == 0 ? queue_to_sample(i, (uint32_t)a.n_blocks, a.scatter, a.scatter_shift)
+                                       : __float_as_uint(a.st_s2[i].w);
+  int x, y;
+  uint32_t frame;
+  slot_to_pixel(a.blocks, a.n_blocks, sslot, a.frame_first, x, y, frame);
+  if (frame != a.frame_first) return; // the log holds one frame
+  const size_t pix = (size_t)y * a.width + x;
+  auto put = [&](int slot, uint32_t r) {
+    const int2 h = a.hits[r];
+    a.log_tri[pix * a.log_slots + slot] = h.x < 0 ? -1 : h.x;
+    a.log_t[pix * a.log_slots + slot] = h.x >= 0 ? __int_as_float(h.y) : INF;
+  };
+  if (a.bounce == 0) {
+    if (a.rq_d[i].w == 0.0f) return; // pixel not owned by this shard: the caller's values stay
+    for (int k = 0; k < a.log_slots; k++) {
+      a.log_tri[pix * a.log_slots + k] = -2;
+      a.log_t[pix * a.log_slots + k] = INF;
+    }
+    put(0, i);
+  } else if (a.mis) {
+    if (a.rq_d[2u * i].w != 0.0f) put(2 * a.bounce - 1, 2u * i);
+    if (a.rq_d[2u * i + 1u].w != 0.0f) put(2 * a.bounce, 2u * i + 1u);
+  } else {
+    put(2 * a.bounce, i);
+  }
+}
+__global__ __launch_bounds__(BLOCK) void pathcolour_kernel(PathLogArgs a, EzrtRenderParams p) {
+  const uint32_t sslot = blockIdx.x * BLOCK + threadIdx.x; // first frame of the chunk
+  if (sslot >= (uint32_t)a.n_blocks * 256u) return;
+  int x, y;
+  uint32_t frame;
+  slot_to_pixel(a.blocks, a.n_blocks, sslot, a.frame_first, x, y, frame);
+  if (!pixel_owned(p, x, y)) return;
+  const float4 c = a.samples[sslot];
+  const size_t pix = (size_t)y * a.width + x;
+  a.log_colour[pix * 3 + 0] = c.x;
+  a.log_colour[pix * 3 + 1] = c.y;
+  a.log_colour[pix * 3 + 2] = c.z;
+}
+
+// ezrt_query_hits through traceq_kernel: caller rays -> a ray queue, hit records -> {tri, t}
+__global__ void query_pack_kernel(const float* rays, uint32_t n, float4* o, float4* d, uint32_t* n_paths) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *n_paths = n;
+  if (i >= n) return;
+  const float* r = rays + (size_t)i * 6;
+  o[i] = make_float4(r[0], r[1], r[2], 0.0f);
+  d[i] = make_float4(r[3], r[4], r[5], 1.0f);
+}
+__global__ void query_unpack_kernel(const int2* hits, uint32_t n, int32_t* tri, float* t) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int2 h = hits[i];
+  tri[i] = h.x < 0 ? -1 : h.x;
+  t[i] = h.x >= 0 ? __int_as_float(h.y) : INF;
+}
+
 } // namespace ezd
