@@ -15,6 +15,7 @@
 #include "ezrt_kernels.h"
 #include "ezrt_wavefront.h"
 #include "ezrt_tracepk.h"
+#include "ezrt_traceq4.h"
 
 using namespace ezd;
 
@@ -74,11 +75,14 @@ struct Tuning {
                            // end is paid twice: 3.81 vs 3.65 ms per C2 frame)
   int sub_frames = 0;      // frames per sub-chunk when pipelined (0: half the call's frames)
   int static_pct = 50;     // share of a trace queue dealt statically to the waves, percent (0: one pool each)
-  int refill_min = 16;     // free lanes a wave waits for before it runs its refill code (publish results, adopt the
+  int refill_min = 24;     // free lanes a wave waits for before it runs its refill code (publish results, adopt the
                            // prefetched ray, prefetch the next): wave-wide code for per-lane events, so batch it (+9 %)
   int split_shade = 2;     // leaving paths and surface interactions shaded by two kernels: 1 from bounce 1 on, 2 always
   int rel_boxes = 1;       // primary rays traverse boxes already translated by the eye
   int steal = 1;           // intra-wave work stealing in traceq_kernel (+ a redo launch for exact ties)
+  int wide4 = 1;           // traceq4_kernel (4-wide collapse of the tree, ezrt_traceq4.h) for the timed stages; 0: the
+                           // binary traceq_kernel.  Instrumented runs (level 1) and scenes whose boxes are not
+                           // nested always use the binary kernel.
   int debug_stages = 0;    // print per-stage queue sizes (synchronises)
   int audit_via_queue = 0; // 1: ezrt_query_hits and ezrt_render_paths run through the TIMED kernels (traceq_kernel with
                            // the template, LDS layout, stealing and redo launch of a render call + the streaming shading
@@ -106,6 +110,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"pipes", &Tuning::pipes, 1, 2},
                               {"sub_frames", &Tuning::sub_frames, 0, 1 << 20},
                               {"scatter", &Tuning::scatter, 0, 8},
+                              {"wide4", &Tuning::wide4, 0, 1},
                               {"debug_stages", &Tuning::debug_stages, 0, 2},
                               {"audit_via_queue", &Tuning::audit_via_queue, 0, 2}};
 Tuning tuning_from_env() {
@@ -138,6 +143,7 @@ struct Pipe {
   DevBuf<uint32_t> redo_slots;
   DevBuf<uint32_t> qheads;      // traceq reservation counters: [launch slot][TRACE_HEADS][TRACE_HEAD_STRIDE]
   DevBuf<float4> inner_rel;     // inner records translated by -eye (primary rays)
+  DevBuf<float4> inner4_rel;    // 4-wide records translated by -eye
   DevBuf<uint32_t> defer_list;  // split shading: paths with a surface interaction, per workgroup
   DevBuf<uint32_t> defer_count;
   hipStream_t stream = nullptr;  // own stream (pipelined calls only)
@@ -150,6 +156,10 @@ struct EzrtScene {
   DevBuf<float4> tri_geom;
   DevBuf<float> tri_ref;
   DevBuf<float4> inner;
+  DevBuf<float4> inner4;      // 4-wide records (ezrt_traceq4.h), breadth-first; empty when the boxes are not nested
+  int n_inner4 = 0;
+  int stack_need4 = 1;        // LDS stack rows the 4-wide traversal can need (exact worst case over hit patterns)
+  uint32_t root4 = 0;
   DevBuf<float4> hdr, cache;
   uint32_t root_ref = 0;
   int env_w = 0, env_h = 0, env_filter = 0;
@@ -353,6 +363,59 @@ void launch_traceq_cfg(EzrtScene* s, const TraceCfg& c, const TraceQArgs& q, boo
   else hipLaunchKernelGGL((traceq_kernel<false, 5>), dim3(trace_grid), dim3(BLOCK), c.lds_t, st, q);
   s->n_trace_launches++;
 }
+// the same for traceq4_kernel: fewer stack rows (stack_need4), 112-B records in LDS
+TraceCfg trace_cfg4(const EzrtScene* s) {
+  TraceCfg c;
+  const Tuning& tu = s->tune;
+  c.lds = (size_t)s->stack_need4 * BLOCK * sizeof(int);
+  const size_t lds_fixed = c.lds + BLOCK * sizeof(int);
+  int blocks_per_cu = tu.trace_wps > 0 ? tu.trace_wps : 5;
+  if ((size_t)blocks_per_cu * lds_fixed > 158 * 1024) blocks_per_cu = (int)((158 * 1024) / lds_fixed);
+  if (blocks_per_cu < 1) blocks_per_cu = 1;
+  size_t lds_budget = (size_t)(158 * 1024) / blocks_per_cu;
+  if (lds_budget > 64 * 1024) lds_budget = 64 * 1024;
+  lds_budget -= lds_budget / 16;
+  int n = lds_budget > lds_fixed ? (int)((lds_budget - lds_fixed) / (N4_LDS_DWORDS * 4)) : 0;
+  if (n > s->n_inner4) n = s->n_inner4;
+  if (n > tu.lds_nodes) n = tu.lds_nodes;
+  if (n < 0) n = 0;
+  c.lds_nodes = n;
+  c.lds_t = lds_fixed + (size_t)n * (N4_LDS_DWORDS * 4);
+  c.blocks_per_cu = blocks_per_cu;
+  c.grid_full = (unsigned)(s->num_cus * blocks_per_cu);
+  return c;
+}
+// whether the timed stages of this scene run traceq4_kernel
+bool use_wide4(const EzrtScene* s) {
+  return s->tune.wide4 && s->n_inner4 > 0 && s->instr == 0 &&
+         ((size_t)s->stack_need4 + 1) * BLOCK * sizeof(int) <= 60 * 1024;
+}
+template <bool REL>
+void launch_traceq4_rel(EzrtScene* s, const TraceCfg& c, const TraceQ4Args& q, hipStream_t st) {
+  const int trace_wps = s->tune.trace_wps;
+  const dim3 grid(c.grid_full), block(BLOCK);
+  if (trace_wps == 8) hipLaunchKernelGGL((traceq4_kernel<8, REL>), grid, block, c.lds_t, st, q);
+  else if (trace_wps == 6) hipLaunchKernelGGL((traceq4_kernel<6, REL>), grid, block, c.lds_t, st, q);
+  else if (trace_wps == 4) hipLaunchKernelGGL((traceq4_kernel<4, REL>), grid, block, c.lds_t, st, q);
+  else hipLaunchKernelGGL((traceq4_kernel<5, REL>), grid, block, c.lds_t, st, q);
+  s->n_trace_launches++;
+}
+// t: the stage's queue arguments as for the binary kernel (knobs already filled); rel: 4-wide records translated by
+// t.origin (or NULL)
+void launch_traceq4_cfg(EzrtScene* s, const TraceCfg& c4, const TraceQArgs& t, const float4* rel, hipStream_t st) {
+  TraceQ4Args A;
+  A.q = t;
+  A.q.stack_entries = (int32_t)(c4.lds / (BLOCK * sizeof(int)));
+  A.q.lds_nodes = 0;
+  A.q.inner_rel = nullptr;
+  A.inner4 = s->inner4.p;
+  A.inner4_rel = rel;
+  A.root4 = s->root4;
+  A.lds_nodes4 = c4.lds_nodes;
+  if (rel) launch_traceq4_rel<true>(s, c4, A, st);
+  else launch_traceq4_rel<false>(s, c4, A, st);
+}
+
 // schedule fields of a traceq launch that come from the knobs (clamped: ADVICE r1)
 void fill_trace_knobs(const EzrtScene* s, const TraceCfg& c, TraceQArgs& t) {
   const Tuning& tu = s->tune;
@@ -366,25 +429,32 @@ void fill_trace_knobs(const EzrtScene* s, const TraceCfg& c, TraceQArgs& t) {
 }
 
 // ---- wavefront pipeline for one chunk of frames (all launches asynchronous on `st`)
+template <int INTEG, int STAGE>
+void launch_shade_is(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
+  if (full) hipLaunchKernelGGL((shade_kernel<INTEG, true, STAGE>), grid, dim3(SHADE_BLOCK), 0, st, a);
+  else hipLaunchKernelGGL((shade_kernel<INTEG, false, STAGE>), grid, dim3(SHADE_BLOCK), 0, st, a);
+}
 template <int INTEG>
 void launch_shade_i(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
-  if (full) hipLaunchKernelGGL((shade_kernel<INTEG, true>), grid, dim3(SHADE_BLOCK), 0, st, a);
-  else hipLaunchKernelGGL((shade_kernel<INTEG, false>), grid, dim3(SHADE_BLOCK), 0, st, a);
+  if (a.bounce == 0) launch_shade_is<INTEG, 0>(a, full, grid, st);
+  else if (a.bounce == 1) launch_shade_is<INTEG, 1>(a, full, grid, st);
+  else launch_shade_is<INTEG, 2>(a, full, grid, st);
 }
-template <int INTEG, bool B0>
+template <int INTEG, int STAGE>
 void launch_shade_split_ib(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st) {
   if (full) {
-    hipLaunchKernelGGL((shade_miss_kernel<INTEG, true, B0>), grid, dim3(SHADE_BLOCK), 0, st, a);
-    hipLaunchKernelGGL((shade_hit_kernel<INTEG, true, B0>), grid_hit, dim3(SHADE_BLOCK), 0, st, a);
+    hipLaunchKernelGGL((shade_miss_kernel<INTEG, true, STAGE>), grid, dim3(SHADE_BLOCK), 0, st, a);
+    hipLaunchKernelGGL((shade_hit_kernel<INTEG, true, STAGE>), grid_hit, dim3(SHADE_BLOCK), 0, st, a);
   } else {
-    hipLaunchKernelGGL((shade_miss_kernel<INTEG, false, B0>), grid, dim3(SHADE_BLOCK), 0, st, a);
-    hipLaunchKernelGGL((shade_hit_kernel<INTEG, false, B0>), grid_hit, dim3(SHADE_BLOCK), 0, st, a);
+    hipLaunchKernelGGL((shade_miss_kernel<INTEG, false, STAGE>), grid, dim3(SHADE_BLOCK), 0, st, a);
+    hipLaunchKernelGGL((shade_hit_kernel<INTEG, false, STAGE>), grid_hit, dim3(SHADE_BLOCK), 0, st, a);
   }
 }
 template <int INTEG>
 void launch_shade_split_i(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st) {
-  if (a.bounce == 0) launch_shade_split_ib<INTEG, true>(a, full, grid, grid_hit, st);
-  else launch_shade_split_ib<INTEG, false>(a, full, grid, grid_hit, st);
+  if (a.bounce == 0) launch_shade_split_ib<INTEG, 0>(a, full, grid, grid_hit, st);
+  else if (a.bounce == 1) launch_shade_split_ib<INTEG, 1>(a, full, grid, grid_hit, st);
+  else launch_shade_split_ib<INTEG, 2>(a, full, grid, grid_hit, st);
 }
 void launch_shade_split(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st) {
   switch (a.p.integrator) {
@@ -496,10 +566,17 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
   a.sobol_tab = pp.sobol_tab.p;
   a.sobol_out = pp.sobol_tab.p;
   a.n_frames = nf;
-  if (s->tune.rel_boxes && s->n_inner > 0) {
+  const bool wide = use_wide4(s);
+  if (!wide && s->tune.rel_boxes && s->n_inner > 0) {
     HIP_TRY(pp.inner_rel.ensure((size_t)s->n_inner * 4));
     hipLaunchKernelGGL(inner_rel_kernel, dim3((unsigned)((s->n_inner + 255) / 256)), dim3(256), 0, st, s->inner.p, s->n_inner,
                        p->eye[0], p->eye[1], p->eye[2], pp.inner_rel.p);
+  }
+  const TraceCfg cfg4 = wide ? trace_cfg4(s) : TraceCfg();
+  if (wide && s->tune.rel_boxes) {
+    HIP_TRY(pp.inner4_rel.ensure((size_t)s->n_inner4 * N4_FLOAT4));
+    hipLaunchKernelGGL(inner4_rel_kernel, dim3((unsigned)((s->n_inner4 + 255) / 256)), dim3(256), 0, st, s->inner4.p, s->n_inner4,
+                       p->eye[0], p->eye[1], p->eye[2], pp.inner4_rel.p);
   }
   hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((n_slots + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, a);
 
@@ -520,7 +597,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     t.n_paths = pp.qcounts.p + b;
     t.rays_per_path = (mis && b > 0) ? 2u : 1u;
     t.const_origin = b == 0 ? 1u : 0u;
-    t.inner_rel = (b == 0 && tu.rel_boxes && s->n_inner > 0) ? pp.inner_rel.p : nullptr;
+    t.inner_rel = (!wide && b == 0 && tu.rel_boxes && s->n_inner > 0) ? pp.inner_rel.p : nullptr;
     t.origin[0] = p->eye[0];
     t.origin[1] = p->eye[1];
     t.origin[2] = p->eye[2];
@@ -575,8 +652,9 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
       t.redo_flag = nullptr;
       launch_traceq(t);
     } else {
-      launch_traceq(t);
-      if (t.steal) { // rays that met an exact distance tie (normally none): reference order, plain stores
+      if (wide) launch_traceq4_cfg(s, cfg4, t, (b == 0 && tu.rel_boxes) ? pp.inner4_rel.p : nullptr, st);
+      else launch_traceq(t);
+      if (t.steal || wide) { // rays that met an exact distance tie, or (4-wide) are not tame -- normally none: reference order, plain stores
         TraceQArgs r = t;
         r.steal = 0u;
         r.count_rays = 0u;
@@ -597,7 +675,9 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
       PathLogArgs g;
       g.hits = pp.hits2[in].p;
       g.rq_d = queue(in).d;
-      g.st_s2 = state(in).s2;
+      const bool compact = p->integrator == EZRT_INTEGRATOR_P5_SOBOL; // (compact_state<50>: see PathState)
+      g.st_slot = compact ? state(in).s1 : state(in).s2;
+      g.slot_comp = compact ? (b == 1 ? 0 : 3) : 3;
       g.n_in = pp.qcounts.p + b;
       g.n_slots = (uint32_t)n_slots;
       g.bounce = b;
@@ -686,6 +766,11 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
       uint32_t dbg[3] = {0, 0, 0};
       HIP_TRY(hipMemcpy(dbg, pp.qcounts.p + 100 + 4 * (b & 3), sizeof dbg, hipMemcpyDeviceToHost));
       HIP_TRY(hipMemset(pp.qcounts.p + 100 + 4 * (b & 3), 0, sizeof dbg));
+      {
+        uint32_t redo_n = 0;
+        HIP_TRY(hipMemcpy(&redo_n, pp.qcounts.p + 128 + b, sizeof redo_n, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[ezrt] stage %d: %u rays re-traced in reference order (exact ties / not tame)\n", b, redo_n);
+      }
       fprintf(stderr, "[ezrt] stage %d: paths_in %u paths_out %u | cum rays %llu pops %llu inner %llu tris %llu | max/ray pops %u tris %u iters %u\n", b, q[0],
               q[1], c[0], c[1], c[2], c[3], dbg[0], dbg[1], dbg[2]);
     }
@@ -800,6 +885,125 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
     memcpy(&rf, &rr, 4);
     q[3] = make_float4(lf, rf, 0.0f, 0.0f);
   }
+  // ---- 4-wide collapse for traceq4_kernel (ezrt_traceq4.h).  Valid only when every box is nested in its
+  // parent's box (true for the reference builders; checked here because the arrays are the caller's).
+  std::vector<float4> inner4;
+  int n_inner4 = 0, stack_need4 = 1;
+  {
+    std::vector<HostNode> hn((size_t)n_nodes);
+    for (int i = 1; i < n_nodes; i++) hn[(size_t)i] = decode_node(nodes, i);
+    bool nested = inner_id[1] >= 0;
+    for (int i = 2; i < n_nodes && nested; i++) { // (the root's own box is never tested)
+      if (inner_id[(size_t)i] < 0) continue;
+      const HostNode& c = hn[(size_t)i];
+      const int kids[2] = {c.left, c.right};
+      for (int k : kids)
+        for (int ax = 0; ax < 3; ax++)
+          if (!(hn[(size_t)k].AA[ax] >= c.AA[ax] && hn[(size_t)k].BB[ax] <= c.BB[ax])) nested = false; // (false on NaN)
+    }
+    if (nested) {
+      auto is_inner = [&](int i) { return inner_id[(size_t)i] >= 0; };
+      auto area = [&](int i) { // schedule heuristic only
+        const HostNode& h = hn[(size_t)i];
+        float ex = h.BB[0] - h.AA[0], ey = h.BB[1] - h.AA[1], ez = h.BB[2] - h.AA[2];
+        float a = ex * ey + ey * ez + ez * ex;
+        return a == a ? a : 0.0f;
+      };
+      auto leaf_pair = [&](int i) { return is_inner(i) && !is_inner(hn[(size_t)i].left) && !is_inner(hn[(size_t)i].right); };
+      struct Rec {
+        int node, m, slot[4];
+      };
+      // a record per reachable "cut root"; slots = a cut of <= 4 descendants: start from the two children and keep
+      // splitting an inner slot (first a pair of leaves -- it would otherwise become a half-empty record of
+      // its own -- else the one with the largest box) while there is room
+      std::vector<Rec> recs;
+      std::vector<int> rec_of((size_t)n_nodes, -1);
+      std::vector<int> todo(1, 1);
+      while (!todo.empty()) {
+        const int x = todo.back();
+        todo.pop_back();
+        Rec r;
+        r.node = x;
+        r.m = 2;
+        r.slot[0] = hn[(size_t)x].left;
+        r.slot[1] = hn[(size_t)x].right;
+        while (r.m < 4) {
+          int pick = -1;
+          bool pick_pair = false;
+          for (int k = 0; k < r.m; k++) {
+            const int g = r.slot[k];
+            if (!is_inner(g)) continue;
+            const bool pr = leaf_pair(g);
+            if (pick < 0 || (pr && !pick_pair) || (pr == pick_pair && area(g) > area(r.slot[pick]))) {
+              pick = k;
+              pick_pair = pr;
+            }
+          }
+          if (pick < 0) break;
+          const int g = r.slot[pick];
+          r.slot[pick] = hn[(size_t)g].left;
+          r.slot[r.m++] = hn[(size_t)g].right;
+        }
+        rec_of[(size_t)x] = (int)recs.size();
+        recs.push_back(r);
+        for (int k = 0; k < r.m; k++)
+          if (is_inner(r.slot[k])) todo.push_back(r.slot[k]);
+      }
+      // stack rows a subtree can need: slots are visited in ascending order (the lowest hit slot next, the others
+      // pushed highest-first), so slot j is entered with at most m-1-j entries pending: need = max_j(m-1-j + need_j);
+      // minimised by ascending need.  Children were created after their parents: walk the records backwards.
+      std::vector<int> need(recs.size(), 0);
+      for (size_t q = recs.size(); q-- > 0;) {
+        Rec& r = recs[q];
+        int nd[4];
+        for (int k = 0; k < r.m; k++) nd[k] = is_inner(r.slot[k]) ? need[(size_t)rec_of[(size_t)r.slot[k]]] : 0;
+        for (int i = 1; i < r.m; i++) // insertion sort by need, stable
+          for (int j = i; j > 0 && nd[j - 1] > nd[j]; j--) {
+            std::swap(nd[j - 1], nd[j]);
+            std::swap(r.slot[j - 1], r.slot[j]);
+          }
+        int w = 0;
+        for (int j = 0; j < r.m; j++) w = std::max(w, r.m - 1 - j + nd[j]);
+        need[q] = w;
+      }
+      stack_need4 = std::max(1, need[0]);
+      // breadth-first numbering: the top of the tree is a prefix (staged in LDS)
+      std::vector<int> order(1, 0), number(recs.size(), -1);
+      number[0] = 0;
+      for (size_t q = 0; q < order.size(); q++) {
+        const Rec& r = recs[(size_t)order[q]];
+        for (int k = 0; k < r.m; k++)
+          if (is_inner(r.slot[k])) {
+            const int c = rec_of[(size_t)r.slot[k]];
+            number[(size_t)c] = (int)order.size();
+            order.push_back(c);
+          }
+      }
+      n_inner4 = (int)recs.size();
+      inner4.assign((size_t)n_inner4 * N4_FLOAT4, make_float4(0, 0, 0, 0));
+      const float qnan = __builtin_nanf("");
+      for (size_t q = 0; q < recs.size(); q++) {
+        const Rec& r = recs[q];
+        float v[7][4];
+        for (int k = 0; k < 4; k++) {
+          uint32_t rf = REF_EMPTY;
+          for (int c = 0; c < 6; c++) v[c][k] = qnan; // unused slot: never hit (see ezrt_traceq4.h)
+          if (k < r.m) {
+            const HostNode& g = hn[(size_t)r.slot[k]];
+            for (int c = 0; c < 3; c++) {
+              v[c][k] = g.AA[c];
+              v[3 + c][k] = g.BB[c];
+            }
+            rf = is_inner(r.slot[k]) ? (uint32_t)number[(size_t)rec_of[(size_t)r.slot[k]]]
+                                     : (LEAF_BIT | ((uint32_t)(g.n - 1) << 24) | (uint32_t)g.index);
+          }
+          memcpy(&v[6][k], &rf, 4);
+        }
+        float4* o = &inner4[(size_t)number[q] * N4_FLOAT4];
+        for (int c = 0; c < 7; c++) o[c] = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+      }
+    }
+  }
   std::vector<float4> geom((size_t)n_tri * 3);
   for (int i = 0; i < n_tri; i++) {
     const float* t = tri + (size_t)i * EZRT_TRI_FLOATS;
@@ -835,6 +1039,13 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
   SC_TRY(hipMemcpy(s->tri_geom.p, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice));
   SC_TRY(hipMemcpy(s->tri_ref.p, tri, (size_t)n_tri * EZRT_TRI_FLOATS * sizeof(float), hipMemcpyHostToDevice));
   SC_TRY(hipMemcpy(s->inner.p, inner.data(), inner.size() * sizeof(float4), hipMemcpyHostToDevice));
+  s->n_inner4 = n_inner4;
+  s->stack_need4 = stack_need4;
+  s->root4 = n_inner4 > 0 ? 0u : s->root_ref;
+  if (n_inner4 > 0) {
+    SC_TRY(s->inner4.ensure(inner4.size()));
+    SC_TRY(hipMemcpy(s->inner4.p, inner4.data(), inner4.size() * sizeof(float4), hipMemcpyHostToDevice));
+  }
   SC_TRY(hipMemset(s->counters.p, 0, (size_t)CTR_SLOTS * EZRT_CTR_COUNT * sizeof(unsigned long long)));
 #undef SC_TRY
   s->stats[0] = n_tri;
@@ -842,7 +1053,8 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
   s->stats[2] = maxd;
   s->stats[3] = leaves;
   s->stats[4] = maxleaf;
-  s->stats[5] = (int64_t)(geom.size() * sizeof(float4) + (size_t)n_tri * 144 + inner.size() * sizeof(float4));
+  s->stats[5] = (int64_t)(geom.size() * sizeof(float4) + (size_t)n_tri * 144 + inner.size() * sizeof(float4) +
+                          inner4.size() * sizeof(float4));
   *out = s;
   return 0;
 }
@@ -1087,7 +1299,14 @@ int ezrt_query_hits(EzrtScene* s, const float* rays, int n_rays, int32_t* tri_id
     t.origin[0] = rays[0];
     t.origin[1] = rays[1];
     t.origin[2] = rays[2];
-    if (shared_origin && s->tune.rel_boxes && s->n_inner > 0) {
+    const bool wide = use_wide4(s);
+    const float4* rel4 = nullptr;
+    if (shared_origin && s->tune.rel_boxes && wide) {
+      HIP_TRY(pp.inner4_rel.ensure((size_t)s->n_inner4 * N4_FLOAT4));
+      hipLaunchKernelGGL(inner4_rel_kernel, dim3((unsigned)((s->n_inner4 + 255) / 256)), dim3(256), 0, nullptr, s->inner4.p,
+                         s->n_inner4, rays[0], rays[1], rays[2], pp.inner4_rel.p);
+      rel4 = pp.inner4_rel.p;
+    } else if (shared_origin && s->tune.rel_boxes && s->n_inner > 0) {
       HIP_TRY(pp.inner_rel.ensure((size_t)s->n_inner * 4));
       hipLaunchKernelGGL(inner_rel_kernel, dim3((unsigned)((s->n_inner + 255) / 256)), dim3(256), 0, nullptr, s->inner.p, s->n_inner,
                          rays[0], rays[1], rays[2], pp.inner_rel.p);
@@ -1104,8 +1323,9 @@ int ezrt_query_hits(EzrtScene* s, const float* rays, int n_rays, int32_t* tri_id
     t.redo_slots = pp.redo_slots.p;
     t.redo_flag = pp.redo_flag.p;
     t.wave_log = nullptr;
-    launch_traceq_cfg(s, cfg, t, false, nullptr);
-    if (t.steal) {
+    if (wide) launch_traceq4_cfg(s, trace_cfg4(s), t, rel4, nullptr);
+    else launch_traceq_cfg(s, cfg, t, false, nullptr);
+    if (t.steal || wide) {
       TraceQArgs r = t;
       r.steal = 0u;
       r.count_rays = 0u;

@@ -1,0 +1,405 @@
+// ezrt_traceq4.h -- traceq4_kernel: the persistent hitBVH of ezrt_traceq.h over a 4-WIDE collapse of the
+// reference's binary tree (the dominant kernel of a render call since round 2).
+//
+// Why this is still the reference's hitBVH (P5/fsh:254-306), bit for bit:
+//
+//  * hitBVH does not prune: a node is visited iff the slab test of its own box and of every ancestor's box
+//    (below the root) says "hit" (d > 0).  For a ray whose origin and 1/direction are finite ("tame") the slab
+//    test is MONOTONE in the box: fl(x - S) and fl(. * inv) are monotone, so for a box G nested in a box C
+//    (AA_C <= AA_G, BB_G <= BB_C componentwise) every per-axis entry distance of G is >= C's and every exit
+//    distance <= C's, hence t0_G >= t0_C, t1_G <= t1_C and  hit(G) = (t1 >= t0 && t1 > 0)  implies hit(C).
+//    (hit(.) is exactly the reference's `hitAABB(..) > 0`: with t1 >= t0 it returns t0 if t0 > 0, else t1.)
+//    The builders make every child box from a subset of its parent's triangles, so boxes ARE nested;
+//    ezrt_scene_create verifies that for caller-supplied arrays and otherwise keeps the binary kernel.
+//    So a node deep in the tree can be tested DIRECTLY, without its ancestors: a 4-wide record holds the
+//    boxes of a "cut" of up to four descendants of one binary node (children, or grandchildren, ...), and a
+//    ray visits exactly the same leaves -- it tests fewer boxes and needs less than half the dependent
+//    memory round trips (C2: 0.43 record visits per binary inner visit).
+//  * The set of triangles tested is unchanged, the result is the minimum t over that set; the reference's
+//    visit order only decides exact ties in t.  This kernel visits children in slot order (no near/far
+//    sorting at all), so EVERY exact tie at the running minimum -- in-lane or between contributors of a
+//    split ray -- sends the ray to the redo list, which the in-order binary kernel re-traces.
+//  * Rays that are not tame (a zero or non-finite direction component: NaNs can arise in the slab test and
+//    monotonicity is lost) go to the redo list unseen.
+//
+// Record (128 B in HBM = one L2 line, 112 B in LDS): AAx[4] AAy[4] AAz[4] BBx[4] BBy[4] BBz[4] ref[4] (pad);
+// an unused slot has an all-NaN box (v_min3/v_max3 of three NaNs is NaN and every compare with it is false:
+// never hit, no extra instruction) and ref = REF_EMPTY.  Slots are ordered by ascending stack need of their
+// subtrees, visited lowest-first with the others pushed in descending order, which bounds the LDS stack by
+// max_j (pending_j + need_j) -- 16 rows on C2 where the binary traversal needs 18.
+//
+// Everything else (persistent waves, prefetched next ray, batched refill, static + dynamic pools, postponed
+// cooperative leaves, intra-wave stealing with the 64-bit atomicMin merge) is ezrt_traceq.h's schedule.
+#pragma once
+#include "ezrt_traceq.h"
+
+namespace ezd {
+
+constexpr uint32_t REF_EMPTY = 0xfffffffdu; // unused slot of a 4-wide record
+constexpr int N4_FLOAT4 = 8;                // record stride in HBM, float4s (7 used)
+constexpr int N4_LDS_DWORDS = 28;           // record stride in LDS: 112 B; 28 r mod 64 hits 16 distinct bank quads
+
+struct TraceQ4Args {
+  TraceQArgs q;             // queue, pools, counters, redo list, knobs (q.lds_nodes is unused here)
+  const float4* inner4;     // 4-wide records, breadth-first
+  const float4* inner4_rel; // q.const_origin only (or NULL): the same with every box translated by -origin
+  uint32_t root4;           // reference of the root: record 0, or the root leaf
+  int32_t lds_nodes4;       // records [0, lds_nodes4) staged in LDS
+};
+
+// 4-wide records with every box translated by -S: (AA - S, BB - S), the subtraction hitAABB does per visit
+__global__ void inner4_rel_kernel(const float4* in, int n, float sx, float sy, float sz, float4* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4* r = in + (size_t)i * N4_FLOAT4;
+  float4* o = out + (size_t)i * N4_FLOAT4;
+  const float s[3] = {sx, sy, sz};
+  for (int k = 0; k < 6; k++) {
+    const float4 v = r[k];
+    const float c = s[k % 3];
+    o[k] = make_float4(v.x - c, v.y - c, v.z - c, v.w - c);
+  }
+  o[6] = r[6];
+  o[7] = r[7];
+}
+
+template <int WPS, bool REL>
+__global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
+  extern __shared__ __attribute__((aligned(16))) int lds_stack[];
+  const TraceQArgs& a = A.q;
+  int* stack = lds_stack + threadIdx.x;
+  const DevScene& sc = a.sc;
+  const uint32_t n_rays = (*a.n_paths) * a.rays_per_path;
+  const int lane = threadIdx.x & 63;
+  if (n_rays == 0) return;
+  int* wsrc = lds_stack + a.stack_entries * BLOCK + (threadIdx.x >> 6) * 64;
+  float4* lds_nodes = reinterpret_cast<float4*>(lds_stack + a.stack_entries * BLOCK + BLOCK);
+  const float4* inner = REL ? A.inner4_rel : A.inner4;
+  for (int k = threadIdx.x; k < A.lds_nodes4 * 7; k += BLOCK) lds_nodes[k] = inner[(k / 7) * N4_FLOAT4 + (k % 7)];
+  __syncthreads();
+
+  // queue indices: see ezrt_traceq.h
+  const uint32_t n_waves = gridDim.x * (BLOCK / 64);
+  uint32_t pool_size = (n_rays + n_waves * a.pool_div - 1) / (n_waves * a.pool_div);
+  pool_size = pool_size > a.pool_max ? a.pool_max : (pool_size < TRACE_POOL_MIN ? TRACE_POOL_MIN : pool_size);
+  uint32_t static_rounds = (uint32_t)(((unsigned long long)n_rays * a.static_pct) / (100ull * n_waves * pool_size));
+  static_rounds = static_rounds < 1u ? 1u : static_rounds;
+  const uint32_t static_total = static_rounds * n_waves * pool_size;
+  const uint32_t wave_id = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+  uint32_t round = 0;
+  uint32_t pool_next = 0, pool_end = 0;
+  bool exhausted = false;
+
+  uint32_t nx_slot = REF_NONE;
+  float4 nx_o = make_float4(0, 0, 0, 0), nx_d = make_float4(0, 0, 0, 0);
+
+  uint32_t slot = 0;
+  f3 S = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
+  float best_t = INF;
+  int32_t best_tri = -1;
+  int sp = 0, sb = 0;
+  bool tie = false;
+  bool shared = false;
+  uint32_t ref = REF_NONE;
+  uint32_t n_counted = 0;
+  unsigned long long* hits64 = reinterpret_cast<unsigned long long*>(a.hits);
+
+  auto to_redo = [&](uint32_t s) { // (rare) the in-order binary kernel decides this ray
+    if (atomicExch(&a.redo_flag[s], 1u) == 0u) a.redo_slots[atomicAdd(a.redo_count, 1u)] = s;
+  };
+  auto finish = [&]() {
+    ref = REF_DONE;
+    sp = 0;
+    sb = 0;
+  };
+  auto publish = [&]() {
+    if (shared) {
+      if (best_tri >= 0) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(best_t) << 32) | (uint32_t)best_tri;
+        const unsigned long long old = atomicMin(&hits64[slot], key);
+        if ((uint32_t)(old >> 32) == (uint32_t)(key >> 32) && (uint32_t)old != (uint32_t)key) tie = true;
+      }
+    } else {
+      a.hits[slot] = make_int2(best_tri, __float_as_int(best_t));
+    }
+    if (tie) to_redo(slot);
+    ref = REF_NONE;
+    tie = false;
+    shared = false;
+  };
+  // a closer (or equally close) hit from a leaf: strict < keeps the first found; an exact tie with a
+  // different triangle is decided by the reference's visit order, which this kernel does not follow
+  auto take = [&](float t, int32_t tri) {
+    if (t < best_t) {
+      best_t = t;
+      best_tri = tri;
+    } else if (t == best_t && tri != best_tri) {
+      tie = true;
+    }
+  };
+
+  const unsigned long long t_start = a.wave_log ? wall_clock64() : 0ull;
+  uint32_t wave_iters = 0, dbg_inner_lanes = 0, dbg_inner_steps = 0, dbg_leaf_lanes = 0, dbg_leaf_rounds = 0, dbg_busy_lanes = 0;
+  for (;;) {
+    wave_iters++;
+    // ---- refill (batched: wave-wide code for per-lane events)
+    const bool want = ref >= REF_DONE;
+    const unsigned long long wantm = ballot(want);
+    if (wantm && ((uint32_t)__popcll(wantm) >= a.refill_min || !ballot(ref < REF_DONE))) {
+      if (ref == REF_DONE) publish();
+      if (want && nx_slot != REF_NONE) {
+        const uint32_t adopted = nx_slot;
+        nx_slot = REF_NONE;
+        if (nx_d.w != 0.0f) {
+          n_counted += a.count_rays;
+          slot = adopted;
+          S = mk(nx_o.x, nx_o.y, nx_o.z);
+          d = mk(nx_d.x, nx_d.y, nx_d.z);
+          inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+          best_t = INF;
+          best_tri = -1;
+          sp = 0;
+          sb = 0;
+          // a ray that is not tame (NaNs possible in the slab test, monotonicity lost) is not this kernel's: it is
+          // "finished" at once with the tie flag set, i.e. published as a miss and appended to the redo list
+          tie = !ray_is_tame(S, inv);
+          ref = tie ? REF_DONE : A.root4;
+        }
+      }
+      const bool need = nx_slot == REF_NONE && !exhausted;
+      const unsigned long long m = ballot(need);
+      if (m) {
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        const uint32_t r = lane_rank(m);
+        uint32_t idx;
+        bool served;
+        if (pool_end - pool_next < cnt) {
+          uint32_t base = n_rays;
+          if (round < static_rounds) {
+            base = (round * n_waves + (wave_id + round * 1223u) % n_waves) * pool_size;
+            round++;
+          } else if (static_total < n_rays) {
+            const uint32_t h = wave_id % TRACE_HEADS;
+            uint32_t k = 0;
+            if (lane == 0) k = atomicAdd(a.head + h * TRACE_HEAD_STRIDE, 1u);
+            k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+            const unsigned long long off = (unsigned long long)(k * TRACE_HEADS + h) * pool_size;
+            base = off < (unsigned long long)(n_rays - static_total) ? static_total + (uint32_t)off : n_rays;
+          }
+          const uint32_t left = pool_end - pool_next;
+          uint32_t take_n = cnt - left;
+          if (take_n > pool_size) take_n = pool_size;
+          idx = (r < left) ? (pool_next + r) : (base + (r - left));
+          served = r < left + take_n;
+          pool_next = base + take_n;
+          pool_end = base + pool_size;
+          if (base >= n_rays) exhausted = true;
+        } else {
+          idx = pool_next + r;
+          served = true;
+          pool_next += cnt;
+          if (pool_next >= n_rays && pool_end >= n_rays) exhausted = true;
+        }
+        if (need && served && idx < n_rays) {
+          uint32_t rs = idx;
+          if (a.slot_map) rs = a.slot_map[idx];
+          nx_slot = rs;
+          nx_o = a.const_origin ? make_float4(a.origin[0], a.origin[1], a.origin[2], 0.0f) : a.rq.o[rs];
+          nx_d = a.rq.d[rs];
+        }
+      }
+    }
+    if (!ballot((ref & nx_slot) != REF_NONE)) break;
+
+    // ---- work stealing: lanes with nothing left to fetch take the oldest pending subtree of a busy lane
+    if (a.steal && exhausted) {
+      const bool idle = (ref & nx_slot) == REF_NONE;
+      const unsigned long long im = ballot(idle);
+      if (im) {
+        const bool rich = sp > sb;
+        const unsigned long long vm = ballot(rich);
+        if (vm) {
+          const int ni = (int)__popcll(im), nv = (int)__popcll(vm);
+          const int n = ni < nv ? ni : nv;
+          const int ir = (int)lane_rank(im), vr = (int)lane_rank(vm);
+          const bool victim = rich && vr < n, thief = idle && ir < n;
+          int give = 0;
+          if (victim) {
+            wsrc[vr] = lane;
+            give = stack[sb * BLOCK];
+            sb++;
+            if (!shared) atomicExch(&hits64[slot], ~0ull); // first split: "no hit yet" (see ezrt_traceq.h)
+            shared = true;
+          }
+          __builtin_amdgcn_wave_barrier();
+          const int src = thief ? wsrc[ir] : lane;
+          const int got = __shfl(give, src, 64);
+          const uint32_t vslot = (uint32_t)__shfl((int)slot, src, 64);
+          const float vsx = __shfl(S.x, src, 64), vsy = __shfl(S.y, src, 64), vsz = __shfl(S.z, src, 64);
+          const float vdx = __shfl(d.x, src, 64), vdy = __shfl(d.y, src, 64), vdz = __shfl(d.z, src, 64);
+          if (thief) {
+            shared = true;
+            slot = vslot;
+            S = mk(vsx, vsy, vsz);
+            d = mk(vdx, vdy, vdz);
+            inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            best_t = INF;
+            best_tri = -1;
+            sp = 0;
+            sb = 0;
+            ref = (uint32_t)got;
+          }
+        }
+      }
+    }
+
+    // ---- inner step: four slab tests (hitAABB, P5/fsh:220-233) on one 4-wide record
+    const bool at_inner = (int32_t)ref >= 0;
+    if (a.wave_log) {
+      const uint32_t ni = (uint32_t)__popcll(ballot(at_inner));
+      dbg_inner_lanes += ni;
+      dbg_inner_steps += ni ? 1u : 0u;
+      dbg_busy_lanes += (uint32_t)__popcll(ballot(ref < REF_DONE));
+    }
+    if (at_inner) {
+      float4 ax, ay, az, bx, by, bz, rf;
+      if (ref < (uint32_t)A.lds_nodes4) { // top of the tree: staged in LDS
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) const v4f lds_v4f;
+        lds_v4f* r = (lds_v4f*)(lds_nodes + ref * 7u);
+        const v4f w0 = r[0], w1 = r[1], w2 = r[2], w3 = r[3], w4 = r[4], w5 = r[5], w6 = r[6];
+        ax = make_float4(w0.x, w0.y, w0.z, w0.w);
+        ay = make_float4(w1.x, w1.y, w1.z, w1.w);
+        az = make_float4(w2.x, w2.y, w2.z, w2.w);
+        bx = make_float4(w3.x, w3.y, w3.z, w3.w);
+        by = make_float4(w4.x, w4.y, w4.z, w4.w);
+        bz = make_float4(w5.x, w5.y, w5.z, w5.w);
+        rf = make_float4(w6.x, w6.y, w6.z, w6.w);
+      } else {
+        const float4* r = inner + (size_t)ref * N4_FLOAT4;
+        ax = r[0];
+        ay = r[1];
+        az = r[2];
+        bx = r[3];
+        by = r[4];
+        bz = r[5];
+        rf = r[6];
+      }
+      auto slab = [&](float axk, float ayk, float azk, float bxk, float byk, float bzk) -> bool {
+        float fx, fy, fz, nx, ny, nz;
+        if (REL) { // boxes already translated by the common origin
+          fx = bxk * inv.x, fy = byk * inv.y, fz = bzk * inv.z;
+          nx = axk * inv.x, ny = ayk * inv.y, nz = azk * inv.z;
+        } else {
+          fx = (bxk - S.x) * inv.x, fy = (byk - S.y) * inv.y, fz = (bzk - S.z) * inv.z;
+          nx = (axk - S.x) * inv.x, ny = (ayk - S.y) * inv.y, nz = (azk - S.z) * inv.z;
+        }
+        const float t1 = hw_min3(hw_max(fx, nx), hw_max(fy, ny), hw_max(fz, nz));
+        const float t0 = hw_max3(hw_min(fx, nx), hw_min(fy, ny), hw_min(fz, nz));
+        return (t1 >= t0) && (t1 > 0.0f); // == hitAABB(..) > 0
+      };
+      const bool h0 = slab(ax.x, ay.x, az.x, bx.x, by.x, bz.x);
+      const bool h1 = slab(ax.y, ay.y, az.y, bx.y, by.y, bz.y);
+      const bool h2 = slab(ax.z, ay.z, az.z, bx.z, by.z, bz.z);
+      const bool h3 = slab(ax.w, ay.w, az.w, bx.w, by.w, bz.w);
+      const uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z),
+                     r3 = __float_as_uint(rf.w);
+      // visit the hit slots in ascending order: continue with the lowest, push the others highest-first
+      if (h3 && (h0 || h1 || h2)) {
+        stack[sp * BLOCK] = (int)r3;
+        sp++;
+      }
+      if (h2 && (h0 || h1)) {
+        stack[sp * BLOCK] = (int)r2;
+        sp++;
+      }
+      if (h1 && h0) {
+        stack[sp * BLOCK] = (int)r1;
+        sp++;
+      }
+      if (h0 || h1 || h2 || h3) {
+        ref = h0 ? r0 : (h1 ? r1 : (h2 ? r2 : r3));
+      } else if (sp > sb) {
+        sp--;
+        ref = (uint32_t)stack[sp * BLOCK];
+      } else {
+        finish();
+      }
+    }
+
+    // ---- leaf phase (hitArray, P5/fsh:238-251): postponed until enough lanes wait at a leaf, or nobody can step
+    const bool at_leaf = (int32_t)ref < -3; // bit 31 set, not REF_NONE / REF_DONE / REF_EMPTY
+    const unsigned long long lm = ballot(at_leaf);
+    if (lm) {
+      const int Lc = (int)__popcll(lm);
+      const bool go = Lc >= a.leaf_threshold || !ballot((int32_t)ref >= 0);
+      if (go) {
+        if (Lc <= 32) {
+          // cooperative: g = 64 / Lc lanes (power of two) per waiting ray
+          const int sh = (Lc <= 1) ? 0 : (32 - __clz(Lc - 1));
+          const int g = 64 >> sh;
+          const uint32_t rank = lane_rank(lm);
+          if (at_leaf) wsrc[rank] = lane;
+          __builtin_amdgcn_wave_barrier();
+          const int grp = lane >> (6 - sh), m = lane & (g - 1);
+          const bool helper = grp < Lc;
+          if (a.wave_log) {
+            dbg_leaf_lanes += (uint32_t)Lc;
+            dbg_leaf_rounds++;
+          }
+          const int src = helper ? wsrc[grp] : lane;
+          const f3 cS = mk(__shfl(S.x, src, 64), __shfl(S.y, src, 64), __shfl(S.z, src, 64));
+          const f3 cd = mk(__shfl(d.x, src, 64), __shfl(d.y, src, 64), __shfl(d.z, src, 64));
+          const uint32_t lref = (uint32_t)__shfl((int)ref, src, 64);
+          unsigned long long key = ~0ull;
+          if (helper) {
+            const int first = (int)(lref & 0x00ffffffu);
+            const int n = (int)((lref >> 24) & 0x7fu) + 1;
+            for (int k = m; k < n; k += g) {
+              float t;
+              if (hit_triangle_t(sc.tri_geom + (size_t)(first + k) * 3, cS, cd, t)) {
+                const unsigned long long k2 = ((unsigned long long)__float_as_uint(t) << 32) | (uint32_t)(first + k);
+                key = k2 < key ? k2 : key;
+              }
+            }
+          }
+          for (int off = 1; off < g; off <<= 1) {
+            const unsigned long long other = __shfl_xor(key, off, 64);
+            key = other < key ? other : key;
+          }
+          const unsigned long long mine = __shfl(key, (int)(rank << (6 - sh)), 64);
+          if (at_leaf && mine != ~0ull) take(__uint_as_float((uint32_t)(mine >> 32)), (int32_t)(uint32_t)mine);
+        } else if (at_leaf) {
+          const int first = (int)(ref & 0x00ffffffu);
+          const int n = (int)((ref >> 24) & 0x7fu) + 1;
+          for (int i = first; i < first + n; i++) {
+            float t;
+            if (hit_triangle_t(sc.tri_geom + (size_t)i * 3, S, d, t)) take(t, i);
+          }
+        }
+        if (at_leaf) {
+          if (sp > sb) {
+            sp--;
+            ref = (uint32_t)stack[sp * BLOCK];
+          } else {
+            finish();
+          }
+        }
+      }
+    }
+  }
+
+  const unsigned long long rr = wave_sum(n_counted);
+  if (lane == 0 && rr) atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_RAYS], rr);
+  if (a.wave_log && lane == 0) {
+    unsigned long long* w = a.wave_log + (size_t)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 8;
+    w[0] = t_start;
+    w[1] = wall_clock64();
+    w[2] = wave_iters | ((unsigned long long)dbg_inner_steps << 32);
+    w[3] = rr | ((unsigned long long)dbg_inner_lanes << 32);
+    w[4] = dbg_leaf_lanes | ((unsigned long long)dbg_leaf_rounds << 32);
+    w[5] = dbg_busy_lanes;
+  }
+}
+
+} // namespace ezd

@@ -32,7 +32,14 @@ struct PathState { // SoA of float4, one slot per live path
   float4* s2; // f_r.xyz, bits(sample slot)
   float4* s3; // Le0.xyz, bits(seed)
   float4* s4; // shadow contribution.xyz, bits(flags)          (integrator 51 only)
+  // Integrator 50 (pdf is the constant 1/(2 pi), no RNG state after ray generation, Le0 = the emission of the
+  // primary hit's triangle) carries a COMPACT state instead -- the shading stages are bound by streaming this state:
+  //   into stage 1 (history = 1 and Lo = 0 exactly):  s0 = f_r.xyz, cosine   s1 = bits(sample slot), bits(tri0)   24 of 32 B
+  //   into stages >= 2:  s0 = history.xyz, cosine   s1 = Lo.xyz, bits(sample slot)   s2 = f_r.xyz, bits(tri0)      48 B
+  // (tri0 = the primary hit's triangle; Le0 is re-read from its material at the path's end)
 };
+template <int INTEG>
+constexpr bool compact_state() { return INTEG == EZRT_INTEGRATOR_P5_SOBOL; }
 struct WfArgs {
   DevScene sc;
   EzrtRenderParams p;
@@ -183,24 +190,26 @@ EZD uint32_t block_rank(bool want, uint32_t* lds /* [SHADE_BLOCK/64 + 1] */, uin
 // What one path hands to the compaction at the end of a shading stage.
 struct ShadeOut {
   bool emit;
-  uint32_t sslot, seed, flags;
+  uint32_t sslot, seed, flags, tri0;
   f3 history, Lo, Le0, f_r, shadowC, rayL, shadowL, P;
   float cosine, pdf;
 };
 
-// One path through stage b (B0: b == 0, the path has no state yet).  PASS 0: everything inline.
+// One path through stage b (STAGE: 0 = b == 0, the path has no state yet; 1 = b == 1; 2 = b >= 2).  PASS 0: everything inline.
 // PASS 1: everything but the surface interaction -- a path whose ray hit a triangle and that
 // is still alive returns true ("deferred") and touches nothing.  PASS 2: the deferred paths, regrouped
 // densely by the caller.  Bounce rays mostly leave the scene (90 % on C2), so without the regrouping
 // every wave ran the ~700-instruction surface code for a handful of its lanes.
-template <int INTEG, bool FULLCTR, int PASS, bool B0>
+template <int INTEG, bool FULLCTR, int PASS, int STAGE>
 EZD bool shade_path(const WfArgs& a, const uint32_t i, bool live, Counters& ctr, uint32_t& n_samples, ShadeOut& o) {
   constexpr bool P5TRI = (INTEG >= 50);
   constexpr bool MIS = (INTEG == EZRT_INTEGRATOR_P5_MIS);
   const DevScene& sc = a.sc;
   const EzrtRenderParams& p = a.p;
   const int b = a.bounce;
-  uint32_t sslot = 0, seed = 0, flags = 0;
+  constexpr bool B0 = (STAGE == 0);
+  constexpr bool COMPACT = compact_state<INTEG>();
+  uint32_t sslot = 0, seed = 0, flags = 0, tri0 = 0;
   f3 history = mk(1, 1, 1), Lo = mk(0, 0, 0), Le0 = mk(0, 0, 0), f_r = mk(0, 0, 0), shadowC = mk(0, 0, 0);
   float cosine = 0.0f, pdf = 1.0f;
   f3 rayL = mk(0, 0, 0), shadowL = mk(0, 0, 0);
@@ -219,10 +228,10 @@ EZD bool shade_path(const WfArgs& a, const uint32_t i, bool live, Counters& ctr,
   int2 sh = make_int2(-1, 0);
   if (!B0) {
     if (PASS != 1) ro4 = a.rq_in.o[rslot]; // (only a surface interaction needs the ray origin)
-    s3 = a.st_in.s3[ii];
+    if (!COMPACT) s3 = a.st_in.s3[ii];
     s0 = a.st_in.s0[ii];
     s1 = a.st_in.s1[ii];
-    s2 = a.st_in.s2[ii];
+    if (!COMPACT || STAGE >= 2) s2 = a.st_in.s2[ii];
     if (MIS) {
       s4 = a.st_in.s4[ii];
       sh = a.hits[2u * ii];
@@ -238,8 +247,8 @@ EZD bool shade_path(const WfArgs& a, const uint32_t i, bool live, Counters& ctr,
     if (PASS != 1) EZ_PIN4(ro4);
     EZ_PIN4(s0);
     EZ_PIN4(s1);
-    EZ_PIN4(s2);
-    EZ_PIN4(s3);
+    if (!COMPACT || STAGE >= 2) EZ_PIN4(s2);
+    if (!COMPACT) EZ_PIN4(s3);
     if (MIS) {
       EZ_PIN4(s4);
       asm volatile("" : "+v"(sh.x), "+v"(sh.y));
@@ -263,6 +272,7 @@ EZD bool shade_path(const WfArgs& a, const uint32_t i, bool live, Counters& ctr,
         if (PASS == 1) return true; // surface interaction: shaded in dense waves (shade_hit_kernel)
         shade_point<P5TRI>(sc, h.x, __int_as_float(h.y), mk(ro4.x, ro4.y, ro4.z), rd, hit);
         Le0 = hit.m.emissive;
+        tri0 = (uint32_t)h.x;
         if (INTEG != EZRT_INTEGRATOR_P5_SOBOL) { // (integrator 50 draws nothing after ray generation: Sobol + CP only)
           // RNG state after the two anti-aliasing draws of ray generation (P5/fsh:315-318, 920-921)
           int x0, y0;
@@ -275,14 +285,33 @@ EZD bool shade_path(const WfArgs& a, const uint32_t i, bool live, Counters& ctr,
       }
     }
   } else {
-    history = mk(s0.x, s0.y, s0.z);
-    cosine = s0.w;
-    Lo = mk(s1.x, s1.y, s1.z);
-    pdf = s1.w;
-    f_r = mk(s2.x, s2.y, s2.z);
-    sslot = __float_as_uint(s2.w);
-    Le0 = mk(s3.x, s3.y, s3.z);
-    seed = __float_as_uint(s3.w);
+    if (COMPACT) {
+      cosine = s0.w;
+      pdf = 1.0f / (2.0f * PI); // (what the bounce wrote: P5/fsh:774)
+      if (STAGE == 1) { // history = (1,1,1), Lo = (0,0,0): the initial values, untouched by bounce 0
+        f_r = mk(s0.x, s0.y, s0.z);
+        sslot = __float_as_uint(s1.x);
+        tri0 = __float_as_uint(s1.y);
+      } else {
+        history = mk(s0.x, s0.y, s0.z);
+        Lo = mk(s1.x, s1.y, s1.z);
+        sslot = __float_as_uint(s1.w);
+        f_r = mk(s2.x, s2.y, s2.z);
+        tri0 = __float_as_uint(s2.w);
+      }
+      // Le0 = the primary hit's emission (getMaterial: texel 6 of its record), needed when the path ends
+      const float* e = sc.tri_ref + (size_t)tri0 * EZRT_TRI_FLOATS + 18;
+      Le0 = mk(e[0], e[1], e[2]);
+    } else {
+      history = mk(s0.x, s0.y, s0.z);
+      cosine = s0.w;
+      Lo = mk(s1.x, s1.y, s1.z);
+      pdf = s1.w;
+      f_r = mk(s2.x, s2.y, s2.z);
+      sslot = __float_as_uint(s2.w);
+      Le0 = mk(s3.x, s3.y, s3.z);
+      seed = __float_as_uint(s3.w);
+    }
     if (MIS) {
       flags = __float_as_uint(s4.w);
       if (flags & FLAG_SHADOW_SHOT) { // P5/fsh:826-841
@@ -395,6 +424,7 @@ EZD bool shade_path(const WfArgs& a, const uint32_t i, bool live, Counters& ctr,
     }
   }
   o.sslot = sslot;
+  o.tri0 = tri0;
   o.seed = seed;
   o.flags = flags;
   o.history = history;
@@ -410,21 +440,22 @@ EZD bool shade_path(const WfArgs& a, const uint32_t i, bool live, Counters& ctr,
   return false;
 }
 
-template <bool MIS>
-EZD void shade_store(const WfArgs& a, const ShadeOut& o, const uint32_t k);
-// compaction of the surviving paths into the next queue: one ballot per wave, one atomic per workgroup
-template <bool MIS>
-EZD void shade_emit(const WfArgs& a, const ShadeOut& o, uint32_t* alloc_lds) {
-  const uint32_t k = block_alloc(a.n_out, o.emit, alloc_lds);
-  if (!o.emit) return;
-  shade_store<MIS>(a, o, k);
-}
-template <bool MIS>
+// FORM: 0 = the general state, 1 = compact state into stage 1, 2 = compact state into stages >= 2 (see PathState)
+template <bool MIS, int FORM>
 EZD void shade_store(const WfArgs& a, const ShadeOut& o, const uint32_t k) {
-  a.st_out.s0[k] = make_float4(o.history.x, o.history.y, o.history.z, o.cosine);
-  a.st_out.s1[k] = make_float4(o.Lo.x, o.Lo.y, o.Lo.z, o.pdf);
-  a.st_out.s2[k] = make_float4(o.f_r.x, o.f_r.y, o.f_r.z, __uint_as_float(o.sslot));
-  a.st_out.s3[k] = make_float4(o.Le0.x, o.Le0.y, o.Le0.z, __uint_as_float(o.seed));
+  if (FORM == 1) {
+    a.st_out.s0[k] = make_float4(o.f_r.x, o.f_r.y, o.f_r.z, o.cosine);
+    a.st_out.s1[k] = make_float4(__uint_as_float(o.sslot), __uint_as_float(o.tri0), 0.0f, 0.0f);
+  } else if (FORM == 2) {
+    a.st_out.s0[k] = make_float4(o.history.x, o.history.y, o.history.z, o.cosine);
+    a.st_out.s1[k] = make_float4(o.Lo.x, o.Lo.y, o.Lo.z, __uint_as_float(o.sslot));
+    a.st_out.s2[k] = make_float4(o.f_r.x, o.f_r.y, o.f_r.z, __uint_as_float(o.tri0));
+  } else {
+    a.st_out.s0[k] = make_float4(o.history.x, o.history.y, o.history.z, o.cosine);
+    a.st_out.s1[k] = make_float4(o.Lo.x, o.Lo.y, o.Lo.z, o.pdf);
+    a.st_out.s2[k] = make_float4(o.f_r.x, o.f_r.y, o.f_r.z, __uint_as_float(o.sslot));
+    a.st_out.s3[k] = make_float4(o.Le0.x, o.Le0.y, o.Le0.z, __uint_as_float(o.seed));
+  }
   const bool shoot = !(o.flags & FLAG_TERMINATE);
   if (MIS) {
     a.st_out.s4[k] = make_float4(o.shadowC.x, o.shadowC.y, o.shadowC.z, __uint_as_float(o.flags));
@@ -437,6 +468,15 @@ EZD void shade_store(const WfArgs& a, const ShadeOut& o, const uint32_t k) {
     a.rq_out.d[k] = make_float4(o.rayL.x, o.rayL.y, o.rayL.z, 1.0f);
   }
 }
+template <int INTEG, int STAGE>
+constexpr int store_form() { return compact_state<INTEG>() ? (STAGE == 0 ? 1 : 2) : 0; }
+// compaction of the surviving paths into the next queue: one ballot per wave, one atomic per workgroup
+template <bool MIS, int FORM>
+EZD void shade_emit(const WfArgs& a, const ShadeOut& o, uint32_t* alloc_lds) {
+  const uint32_t k = block_alloc(a.n_out, o.emit, alloc_lds);
+  if (!o.emit) return;
+  shade_store<MIS, FORM>(a, o, k);
+}
 
 // Split shading (split_shade): most paths of a stage leave the scene, and everything a leaving path
 // needs (state loads, environment lookup, sample store) fits in 45 registers -- so that part runs as
@@ -445,8 +485,9 @@ EZD void shade_store(const WfArgs& a, const ShadeOut& o, const uint32_t k) {
 // k of the second kernel takes the list of workgroup k of the first): no global atomic and no barrier
 // in the first kernel -- one list-tail atomic per 512 paths was 32 k atomics on the primary stage, four
 // times what the counter sustains in the time the kernel needs.
-template <int INTEG, bool FULLCTR, bool B0>
+template <int INTEG, bool FULLCTR, int STAGE>
 __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MISS_WAVES) void shade_miss_kernel(WfArgs a) {
+  constexpr bool B0 = (STAGE == 0);
   __shared__ uint32_t list_tail;
   const uint32_t n_in = B0 ? a.n_slots : *a.n_in;
   const uint32_t stride = gridDim.x * SHADE_BLOCK;
@@ -459,7 +500,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MISS_WAVES) void shade_miss_kern
   const int lane = threadIdx.x & 63;
   for (uint32_t k = 0, i = blockIdx.x * SHADE_BLOCK + threadIdx.x; k < iters; k++, i += stride) {
     ShadeOut o;
-    const bool deferred = shade_path<INTEG, FULLCTR, 1, B0>(a, i, i < n_in, ctr, n_samples, o);
+    const bool deferred = shade_path<INTEG, FULLCTR, 1, STAGE>(a, i, i < n_in, ctr, n_samples, o);
     const unsigned long long m = ballot(deferred);
     if (m) {
       uint32_t base = 0;
@@ -484,9 +525,11 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MISS_WAVES) void shade_miss_kern
 }
 
 // launched with the grid of shade_miss_kernel
-template <int INTEG, bool FULLCTR, bool B0>
+template <int INTEG, bool FULLCTR, int STAGE>
 __global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_hit_kernel(WfArgs a) {
   __shared__ uint32_t alloc_lds[SHADE_BLOCK / 64 + 1];
+  constexpr bool B0 = (STAGE == 0);
+  constexpr int FORM = store_form<INTEG, STAGE>();
   constexpr bool MIS = (INTEG == EZRT_INTEGRATOR_P5_MIS);
   const uint32_t n_in = B0 ? a.n_slots : *a.n_in;
   const uint32_t stride = gridDim.x * SHADE_BLOCK;
@@ -505,16 +548,16 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_hit_kernel(WfArgs a) {
     const uint32_t base = alloc_lds[0];
     for (uint32_t j = threadIdx.x; j < cnt; j += SHADE_BLOCK) {
       ShadeOut o;
-      shade_path<INTEG, FULLCTR, 2, B0>(a, list[j], true, ctr, n_samples, o);
-      if (o.emit) shade_store<MIS>(a, o, base + j);
+      shade_path<INTEG, FULLCTR, 2, STAGE>(a, list[j], true, ctr, n_samples, o);
+      if (o.emit) shade_store<MIS, FORM>(a, o, base + j);
     }
   } else {
     for (uint32_t j0 = 0; j0 < cnt; j0 += SHADE_BLOCK) { // (workgroup-uniform trip count: barriers inside)
       const uint32_t j = j0 + threadIdx.x;
       ShadeOut o;
       o.emit = false;
-      if (j < cnt) shade_path<INTEG, FULLCTR, 2, B0>(a, list[j], true, ctr, n_samples, o);
-      shade_emit<MIS>(a, o, alloc_lds);
+      if (j < cnt) shade_path<INTEG, FULLCTR, 2, STAGE>(a, list[j], true, ctr, n_samples, o);
+      shade_emit<MIS, FORM>(a, o, alloc_lds);
     }
   }
   if (FULLCTR) {
@@ -527,13 +570,13 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_hit_kernel(WfArgs a) {
   }
 }
 
-template <int INTEG, bool FULLCTR>
+template <int INTEG, bool FULLCTR, int STAGE>
 __global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_kernel(WfArgs a) {
   __shared__ uint32_t alloc_lds[SHADE_BLOCK / 64 + 1];
   __shared__ uint32_t defer_list[SHADE_BLOCK];
   constexpr bool MIS = (INTEG == EZRT_INTEGRATOR_P5_MIS);
-  const int b = a.bounce;
-  const uint32_t n_in = (b == 0) ? a.n_slots : *a.n_in;
+  constexpr int FORM = store_form<INTEG, STAGE>();
+  const uint32_t n_in = (STAGE == 0) ? a.n_slots : *a.n_in;
   const uint32_t stride = gridDim.x * SHADE_BLOCK;
   const uint32_t n_round = (n_in + stride - 1) / stride * stride; // keep workgroups whole for the barriers
   Counters ctr = {0, 0, 0, 0, 0, 0, 0};
@@ -541,11 +584,11 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_kernel(WfArgs a) {
 
   for (uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x; i < n_round; i += stride) {
     ShadeOut o;
-    if (b == 0) {
-      shade_path<INTEG, FULLCTR, 0, true>(a, i, i < n_in, ctr, n_samples, o);
-      shade_emit<MIS>(a, o, alloc_lds);
+    if (STAGE == 0) {
+      shade_path<INTEG, FULLCTR, 0, 0>(a, i, i < n_in, ctr, n_samples, o);
+      shade_emit<MIS, FORM>(a, o, alloc_lds);
     } else {
-      const bool deferred = shade_path<INTEG, FULLCTR, 1, false>(a, i, i < n_in, ctr, n_samples, o);
+      const bool deferred = shade_path<INTEG, FULLCTR, 1, STAGE>(a, i, i < n_in, ctr, n_samples, o);
       uint32_t n_def = 0;
       const uint32_t k = block_rank(deferred, alloc_lds, n_def);
       if (deferred) defer_list[k] = i;
@@ -553,8 +596,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_kernel(WfArgs a) {
       const bool has = threadIdx.x < n_def; // (n_def <= SHADE_BLOCK: one dense round)
       const uint32_t j = has ? defer_list[threadIdx.x] : 0u;
       o.emit = false;
-      if (has) shade_path<INTEG, FULLCTR, 2, false>(a, j, true, ctr, n_samples, o);
-      shade_emit<MIS>(a, o, alloc_lds);
+      if (has) shade_path<INTEG, FULLCTR, 2, STAGE>(a, j, true, ctr, n_samples, o);
+      shade_emit<MIS, FORM>(a, o, alloc_lds);
     }
   }
 
@@ -577,7 +620,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_kernel(WfArgs a) {
 struct PathLogArgs {
   const int2* hits;      // hit records of the stage's ray queue
   const float4* rq_d;    // its ray directions (.w = 0: slot not shot)
-  const float4* st_s2;   // path state of the queue (.w = bits(sample slot)); unused for stage 0
+  const float4* st_slot; // the path-state array that holds bits(sample slot) for this stage, and in which component
+  int32_t slot_comp;     //   (general state: s2.w; compact state of integrator 50: s1.x into stage 1, s1.w later)
   const uint32_t* n_in;  // paths in the queue (stage >= 1)
   uint32_t n_slots;      // stage 0: pixel-samples of the chunk
   int32_t bounce;        // stage index b (0 = primary rays)
@@ -597,7 +641,7 @@ __global__ __launch_bounds__(BLOCK) void pathlog_kernel(PathLogArgs a) {
   const uint32_t n = a.bounce == 0 ? a.n_slots : *a.n_in;
   if (i >= n) return;
   const uint32_t sslot = a.bounce == 0 ? queue_to_sample(i, (uint32_t)a.n_blocks, a.scatter, a.scatter_shift)
-                                       : __float_as_uint(a.st_s2[i].w);
+                                       : __float_as_uint((&a.st_slot[i].x)[a.slot_comp]);
   int x, y;
   uint32_t frame;
   slot_to_pixel(a.blocks, a.n_blocks, sslot, a.frame_first, x, y, frame);

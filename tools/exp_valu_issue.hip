@@ -1,0 +1,161 @@
+// exp_valu_issue.hip -- settles the VALU issue ceiling traceq_kernel is priced against (VERDICT r1,
+// weak #4): how many wave64 VALU instructions per cycle does one gfx950 SIMD issue?
+//
+//   for each opcode: a straight-line block of 256 independent instructions (8 accumulators, no
+//   dependency closer than 8 instructions), repeated `iters` times; W waves per SIMD (W = 1, 2, 4, 8:
+//   workgroups of 256 threads = one wave per SIMD, W workgroups per CU, all 256 CUs);
+//   cycles = s_memtime (shader clock) around the loop, per wave; the SIMD's issue rate =
+//   W * instructions / max-wave-cycles.
+//
+// Build + run on the GPU box:  hipcc --offload-arch=gfx950 -O2 -o /tmp/exp_valu tools/exp_valu_issue.hip && /tmp/exp_valu
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+#define REP8(x) x x x x x x x x
+enum { OP_ADD, OP_MUL, OP_FMA, OP_MAX, OP_MIN3, OP_CNDMASK, OP_ADDU, OP_PKFMA, OP_RCP, OP_MIX, OP_CND64, OP_CMPCND, OP_ADDCND, OP_MAXE64, OP_MOV, OP_CNDVCC_NOCLOB, OP_CNDVCC_E64, OP_CMPVCC_CND, N_OPS };
+static const char* kNames[N_OPS] = {"v_add_f32", "v_mul_f32", "v_fma_f32", "v_max_f32", "v_min3_f32", "v_cndmask_b32",
+                                    "v_add_u32", "v_pk_fma_f32", "v_rcp_f32", "mix(add,mul,max,min3)", "v_cndmask_b32_e64 s[]", "v_cmp_lt+v_cndmask", "v_add,v_cndmask altern.", "v_max_f32_e64", "v_mov_b32", "v_cndmask_e32 vcc (no clobber)", "v_cndmask_e64 vcc", "v_cmp_e32 vcc + v_cndmask_e32 vcc"};
+
+template <int OP>
+__global__ __launch_bounds__(256) void issue_kernel(int iters, float seed, unsigned long long* cycles, float* sink) {
+  float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  float k = 1.0000001f;
+  typedef float v2 __attribute__((ext_vector_type(2)));
+  v2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, pk = {k, k};
+  unsigned long long msk = 0x5555aaaa3333ccccull ^ (unsigned long long)iters, m0 = 0, m1 = 0;
+  __builtin_amdgcn_s_barrier();
+  const unsigned long long r0 = wall_clock64();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; i++) {
+#define Q4(ins) asm volatile(ins " %0, %0, %4\n\t" ins " %1, %1, %4\n\t" ins " %2, %2, %4\n\t" ins " %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k)); \
+                asm volatile(ins " %0, %0, %4\n\t" ins " %1, %1, %4\n\t" ins " %2, %2, %4\n\t" ins " %3, %3, %4" : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k));
+#define Q4T(ins) asm volatile(ins " %0, %0, %4, %4\n\t" ins " %1, %1, %4, %4\n\t" ins " %2, %2, %4, %4\n\t" ins " %3, %3, %4, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k)); \
+                 asm volatile(ins " %0, %0, %4, %4\n\t" ins " %1, %1, %4, %4\n\t" ins " %2, %2, %4, %4\n\t" ins " %3, %3, %4, %4" : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k));
+    if (OP == OP_ADD) { REP8(REP8(Q4("v_add_f32")) ) }
+    if (OP == OP_MUL) { REP8(REP8(Q4("v_mul_f32")) ) }
+    if (OP == OP_MAX) { REP8(REP8(Q4("v_max_f32")) ) }
+    if (OP == OP_ADDU) { REP8(REP8(Q4("v_add_u32")) ) }
+    if (OP == OP_FMA) { REP8(REP8(Q4T("v_fma_f32")) ) }
+    if (OP == OP_MIN3) { REP8(REP8(Q4T("v_min3_f32")) ) }
+    if (OP == OP_CNDMASK) {
+      REP8(REP8(asm volatile("v_cndmask_b32 %0, %0, %4, vcc\n\tv_cndmask_b32 %1, %1, %4, vcc\n\tv_cndmask_b32 %2, %2, %4, vcc\n\tv_cndmask_b32 %3, %3, %4, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k) : "vcc");
+                asm volatile("v_cndmask_b32 %0, %0, %4, vcc\n\tv_cndmask_b32 %1, %1, %4, vcc\n\tv_cndmask_b32 %2, %2, %4, vcc\n\tv_cndmask_b32 %3, %3, %4, vcc" : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k) : "vcc");))
+    }
+    if (OP == OP_CND64) { // mask in a plain SGPR pair (what compiled selects use)
+      REP8(REP8(asm volatile("v_cndmask_b32_e64 %0, %0, %4, %5\n\tv_cndmask_b32_e64 %1, %1, %4, %5\n\tv_cndmask_b32_e64 %2, %2, %4, %5\n\tv_cndmask_b32_e64 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k), "s"(msk));
+                asm volatile("v_cndmask_b32_e64 %0, %0, %4, %5\n\tv_cndmask_b32_e64 %1, %1, %4, %5\n\tv_cndmask_b32_e64 %2, %2, %4, %5\n\tv_cndmask_b32_e64 %3, %3, %4, %5" : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k), "s"(msk));))
+    }
+    if (OP == OP_CMPCND) { // compare into an SGPR pair, select on it: 2 instructions per statement
+      REP8(REP8(asm volatile("v_cmp_lt_f32_e64 %2, %0, %4\n\tv_cndmask_b32_e64 %0, %0, %4, %2\n\tv_cmp_lt_f32_e64 %3, %1, %4\n\tv_cndmask_b32_e64 %1, %1, %4, %3" : "+v"(a0), "+v"(a1), "=&s"(m0), "=&s"(m1) : "v"(k));
+                asm volatile("v_cmp_lt_f32_e64 %2, %0, %4\n\tv_cndmask_b32_e64 %0, %0, %4, %2\n\tv_cmp_lt_f32_e64 %3, %1, %4\n\tv_cndmask_b32_e64 %1, %1, %4, %3" : "+v"(a2), "+v"(a3), "=&s"(m0), "=&s"(m1) : "v"(k));))
+    }
+    if (OP == OP_ADDCND) {
+      REP8(REP8(asm volatile("v_add_f32 %0, %0, %4\n\tv_cndmask_b32_e64 %1, %1, %4, %5\n\tv_add_f32 %2, %2, %4\n\tv_cndmask_b32_e64 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k), "s"(msk));
+                asm volatile("v_add_f32 %0, %0, %4\n\tv_cndmask_b32_e64 %1, %1, %4, %5\n\tv_add_f32 %2, %2, %4\n\tv_cndmask_b32_e64 %3, %3, %4, %5" : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k), "s"(msk));))
+    }
+    if (OP == OP_CNDVCC_NOCLOB) { // vcc loaded once per trip; the compiler is not told (no s_nop padding between statements)
+      asm volatile("s_mov_b64 vcc, %0" : : "s"(msk));
+      REP8(REP8(asm volatile("v_cndmask_b32_e32 %0, %0, %4, vcc\n\tv_cndmask_b32_e32 %1, %1, %4, vcc\n\tv_cndmask_b32_e32 %2, %2, %4, vcc\n\tv_cndmask_b32_e32 %3, %3, %4, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k));
+                asm volatile("v_cndmask_b32_e32 %0, %0, %4, vcc\n\tv_cndmask_b32_e32 %1, %1, %4, vcc\n\tv_cndmask_b32_e32 %2, %2, %4, vcc\n\tv_cndmask_b32_e32 %3, %3, %4, vcc" : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k));))
+    }
+    if (OP == OP_CNDVCC_E64) {
+      asm volatile("s_mov_b64 vcc, %0" : : "s"(msk));
+      REP8(REP8(asm volatile("v_cndmask_b32_e64 %0, %0, %4, vcc\n\tv_cndmask_b32_e64 %1, %1, %4, vcc\n\tv_cndmask_b32_e64 %2, %2, %4, vcc\n\tv_cndmask_b32_e64 %3, %3, %4, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k));
+                asm volatile("v_cndmask_b32_e64 %0, %0, %4, vcc\n\tv_cndmask_b32_e64 %1, %1, %4, vcc\n\tv_cndmask_b32_e64 %2, %2, %4, vcc\n\tv_cndmask_b32_e64 %3, %3, %4, vcc" : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k));))
+    }
+    if (OP == OP_CMPVCC_CND) { // what compiled selects look like: v_cmp_e32 -> vcc, v_cndmask_e32 <- vcc
+      REP8(REP8(asm volatile("v_cmp_lt_f32_e32 vcc, %0, %2\n\tv_cndmask_b32_e32 %0, %0, %2, vcc\n\tv_cmp_lt_f32_e32 vcc, %1, %2\n\tv_cndmask_b32_e32 %1, %1, %2, vcc" : "+v"(a0), "+v"(a1) : "v"(k) : "vcc");
+                asm volatile("v_cmp_lt_f32_e32 vcc, %0, %2\n\tv_cndmask_b32_e32 %0, %0, %2, vcc\n\tv_cmp_lt_f32_e32 vcc, %1, %2\n\tv_cndmask_b32_e32 %1, %1, %2, vcc" : "+v"(a2), "+v"(a3) : "v"(k) : "vcc");))
+    }
+    if (OP == OP_MAXE64) { REP8(REP8(Q4("v_max_f32_e64")) ) }
+    if (OP == OP_MOV) {
+      REP8(REP8(asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %4\n\tv_mov_b32 %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k));
+                asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %4\n\tv_mov_b32 %3, %4" : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k));))
+    }
+    if (OP == OP_RCP) {
+      REP8(REP8(asm volatile("v_rcp_f32 %0, %0\n\tv_rcp_f32 %1, %1\n\tv_rcp_f32 %2, %2\n\tv_rcp_f32 %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+                asm volatile("v_rcp_f32 %0, %0\n\tv_rcp_f32 %1, %1\n\tv_rcp_f32 %2, %2\n\tv_rcp_f32 %3, %3" : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));))
+    }
+    if (OP == OP_PKFMA) { // 4 packed instructions per statement pair = 8 fp32 FMAs each... counted as INSTRUCTIONS (256/block)
+      REP8(REP8(asm volatile("v_pk_fma_f32 %0, %0, %4, %4\n\tv_pk_fma_f32 %1, %1, %4, %4\n\tv_pk_fma_f32 %2, %2, %4, %4\n\tv_pk_fma_f32 %3, %3, %4, %4" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pk));
+                asm volatile("v_pk_fma_f32 %0, %0, %4, %4\n\tv_pk_fma_f32 %1, %1, %4, %4\n\tv_pk_fma_f32 %2, %2, %4, %4\n\tv_pk_fma_f32 %3, %3, %4, %4" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pk));))
+    }
+    if (OP == OP_MIX) { // the slab test's mix
+      REP8(REP8(asm volatile("v_sub_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %4\n\tv_max_f32 %2, %2, %4\n\tv_min3_f32 %3, %3, %4, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k));
+                asm volatile("v_sub_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %4\n\tv_min_f32 %2, %2, %4\n\tv_max3_f32 %3, %3, %4, %4" : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k));))
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = wall_clock64();
+  if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+  if (threadIdx.x == 0 && blockIdx.x == 0) { cycles[gridDim.x * 4] = t1 - t0; cycles[gridDim.x * 4 + 1] = r1 - r0; }
+  if (m0 + m1 == 12345ull) sink[1] = 1.0f;
+  float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
+  if (s == 123.456f) sink[0] = s;
+}
+
+template <int OP>
+void run(int cus) {
+  const int iters = 200;
+  const double n_instr = 512.0 * iters; // per wave: 8 x 8 x 8 instructions per loop trip
+  unsigned long long* dc;
+  float* ds;
+  for (int W : {1, 2, 4, 8}) {
+    const int blocks = cus * W;
+    hipMalloc(&dc, sizeof(unsigned long long) * (blocks * 4 + 2));
+    hipMalloc(&ds, 4);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(issue_kernel<OP>, dim3(blocks), dim3(256), 0, 0, 10, 1.0f, dc, ds); // warm-up
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(issue_kernel<OP>, dim3(blocks), dim3(256), 0, 0, iters, 1.0f, dc, ds);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> c(blocks * 4 + 2);
+    hipMemcpy(c.data(), dc, c.size() * 8, hipMemcpyDeviceToHost);
+    const double mhz = c[blocks * 4 + 1] ? (double)c[blocks * 4] / ((double)c[blocks * 4 + 1] * 0.01) : 0.0; // s_memtime ticks per us of the 100 MHz clock
+    c.resize(blocks * 4);
+    std::sort(c.begin(), c.end());
+    const double med = (double)c[c.size() / 2], mx = (double)c.back();
+    // s_memtime ticks at 100 MHz on gfx9; convert with the wall time of the launch
+    const double instr_per_s_chip = n_instr * blocks * 4 / (ms * 1e-3);
+    printf("%-22s W=%d  wall %.3f ms  chip %.3f T wave-instr/s  per SIMD %.3f G wave-instr/s  memtime ticks/wave med %.0f max %.0f  memtime %.0f MHz  min cycles/instr/SIMD %.2f\n",
+           kNames[OP], W, ms, instr_per_s_chip * 1e-12, instr_per_s_chip / (cus * 4) * 1e-9, med, mx, mhz, mx / (n_instr * W));
+    hipFree(dc);
+    hipFree(ds);
+  }
+}
+
+int main() {
+  hipDeviceProp_t prop;
+  hipGetDeviceProperties(&prop, 0);
+  const int cus = prop.multiProcessorCount;
+  printf("device %s, %d CUs, clock %.0f MHz (reported max)\n", prop.gcnArchName, cus, prop.clockRate / 1000.0);
+  printf("reading: per-SIMD G wave-instr/s / clock GHz = wave64 instructions per cycle per SIMD (0.5 = 2-cycle issue, 0.25 = 4-cycle)\n");
+  run<OP_ADD>(cus);
+  run<OP_MUL>(cus);
+  run<OP_FMA>(cus);
+  run<OP_MAX>(cus);
+  run<OP_MIN3>(cus);
+  run<OP_CNDMASK>(cus);
+  run<OP_ADDU>(cus);
+  run<OP_PKFMA>(cus);
+  run<OP_RCP>(cus);
+  run<OP_MIX>(cus);
+  run<OP_CND64>(cus);
+  run<OP_CMPCND>(cus);
+  run<OP_ADDCND>(cus);
+  run<OP_MAXE64>(cus);
+  run<OP_MOV>(cus);
+  run<OP_CNDVCC_NOCLOB>(cus);
+  run<OP_CNDVCC_E64>(cus);
+  run<OP_CMPVCC_CND>(cus);
+  return 0;
+}
