@@ -83,6 +83,8 @@ struct Tuning {
   int wide4 = 1;           // traceq4_kernel (4-wide collapse of the tree, ezrt_traceq4.h) for the timed stages; 0: the
                            // binary traceq_kernel.  Instrumented runs (level 1) and scenes whose boxes are not
                            // nested always use the binary kernel.
+  int tail_stage = 0;      // from this stage on (>= 2; 0: never -- the default: measured 1.95 ms vs 0.43 ms for stages 2-4 of C2) the surviving paths finish in tail_kernel, one lane per
+                           // path, instead of one trace + shading stage per bounce (ezrt_wavefront.h)
   int debug_stages = 0;    // print per-stage queue sizes (synchronises)
   int audit_via_queue = 0; // 1: ezrt_query_hits and ezrt_render_paths run through the TIMED kernels (traceq_kernel with
                            // the template, LDS layout, stealing and redo launch of a render call + the streaming shading
@@ -111,6 +113,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"sub_frames", &Tuning::sub_frames, 0, 1 << 20},
                               {"scatter", &Tuning::scatter, 0, 8},
                               {"wide4", &Tuning::wide4, 0, 1},
+                              {"tail_stage", &Tuning::tail_stage, 0, 64},
                               {"debug_stages", &Tuning::debug_stages, 0, 2},
                               {"audit_via_queue", &Tuning::audit_via_queue, 0, 2}};
 Tuning tuning_from_env() {
@@ -588,8 +591,25 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
   const unsigned shade_grid_max = 2048u * 1024u / SHADE_BLOCK; // 8 workgroup-iterations' worth of resident threads
   if (shade_grid > shade_grid_max) shade_grid = shade_grid_max;
 
+  const int tail_from = (!full && !plog && !debug_stages && tu.tail_stage >= 2) ? tu.tail_stage : (1 << 30);
   for (int b = 0; b <= p->max_bounce; b++) {
     const int in = b & 1, out = in ^ 1;
+    if (b >= tail_from) { // the few paths still alive finish here, one lane each
+      a.rq_in = queue(in);
+      a.st_in = state(in);
+      a.n_in = pp.qcounts.p + b;
+      a.bounce = b;
+      unsigned tg = (unsigned)(s->num_cus * 8);
+      if ((size_t)tg * BLOCK > n_slots) tg = (unsigned)((n_slots + BLOCK - 1) / BLOCK);
+      const size_t tl = stack_lds_bytes(s);
+      switch (p->integrator) {
+        case EZRT_INTEGRATOR_P3_DIFFUSE: hipLaunchKernelGGL((tail_kernel<EZRT_INTEGRATOR_P3_DIFFUSE>), dim3(tg), dim3(BLOCK), tl, st, a, s->depth); break;
+        case EZRT_INTEGRATOR_P4_DISNEY: hipLaunchKernelGGL((tail_kernel<EZRT_INTEGRATOR_P4_DISNEY>), dim3(tg), dim3(BLOCK), tl, st, a, s->depth); break;
+        case EZRT_INTEGRATOR_P5_SOBOL: hipLaunchKernelGGL((tail_kernel<EZRT_INTEGRATOR_P5_SOBOL>), dim3(tg), dim3(BLOCK), tl, st, a, s->depth); break;
+        default: hipLaunchKernelGGL((tail_kernel<EZRT_INTEGRATOR_P5_MIS>), dim3(tg), dim3(BLOCK), tl, st, a, s->depth); break;
+      }
+      break;
+    }
     TraceQArgs t;
     t.sc = a.sc;
     t.rq = queue(in);
@@ -734,7 +754,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
         unsigned long long t0 = ~0ull;
         for (size_t i = 0; i < nw; i++)
           if (w[i * 8] && w[i * 8] < t0) t0 = w[i * 8];
-        unsigned long long s_it = 0, s_is = 0, s_il = 0, s_ll = 0, s_lr = 0, s_busy = 0;
+        unsigned long long s_it = 0, s_is = 0, s_il = 0, s_ll = 0, s_lr = 0, s_busy = 0, s_rf = 0, s_st = 0;
         std::vector<double> endt, life, its, rays, startt;
         for (size_t i = 0; i < nw; i++)
           if (w[i * 8]) {
@@ -749,6 +769,8 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
             s_ll += (uint32_t)w[i * 8 + 4];
             s_lr += w[i * 8 + 4] >> 32;
             s_busy += w[i * 8 + 5];
+            s_rf += (uint32_t)w[i * 8 + 6];
+            s_st += w[i * 8 + 6] >> 32;
           }
         auto pct = [](std::vector<double>& v, double q) {
           if (v.empty()) return 0.0;
@@ -762,6 +784,8 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
         fprintf(stderr, "[ezrt]   iterations %llu: lanes with a ray %.1f/64 | inner steps in %.0f %% of them, %.1f lanes each | cooperative leaf rounds in %.0f %%, %.1f rays each\n",
                 s_it, (double)s_busy / (double)(s_it ? s_it : 1), 100.0 * (double)s_is / (double)(s_it ? s_it : 1), (double)s_il / (double)(s_is ? s_is : 1),
                 100.0 * (double)s_lr / (double)(s_it ? s_it : 1), (double)s_ll / (double)(s_lr ? s_lr : 1));
+        fprintf(stderr, "[ezrt]   refill block in %.0f %% of the iterations, steal block in %.0f %%\n", 100.0 * (double)s_rf / (double)(s_it ? s_it : 1),
+                100.0 * (double)s_st / (double)(s_it ? s_it : 1));
       }
       uint32_t dbg[3] = {0, 0, 0};
       HIP_TRY(hipMemcpy(dbg, pp.qcounts.p + 100 + 4 * (b & 3), sizeof dbg, hipMemcpyDeviceToHost));

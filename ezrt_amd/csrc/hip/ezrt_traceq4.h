@@ -139,13 +139,15 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
   };
 
   const unsigned long long t_start = a.wave_log ? wall_clock64() : 0ull;
-  uint32_t wave_iters = 0, dbg_inner_lanes = 0, dbg_inner_steps = 0, dbg_leaf_lanes = 0, dbg_leaf_rounds = 0, dbg_busy_lanes = 0;
+  uint32_t wave_iters = 0, dbg_inner_lanes = 0, dbg_inner_steps = 0, dbg_leaf_lanes = 0, dbg_leaf_rounds = 0, dbg_busy_lanes = 0,
+           dbg_refills = 0, dbg_steals = 0;
   for (;;) {
     wave_iters++;
     // ---- refill (batched: wave-wide code for per-lane events)
     const bool want = ref >= REF_DONE;
     const unsigned long long wantm = ballot(want);
     if (wantm && ((uint32_t)__popcll(wantm) >= a.refill_min || !ballot(ref < REF_DONE))) {
+      if (a.wave_log) dbg_refills++;
       if (ref == REF_DONE) publish();
       if (want && nx_slot != REF_NONE) {
         const uint32_t adopted = nx_slot;
@@ -219,6 +221,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
         const bool rich = sp > sb;
         const unsigned long long vm = ballot(rich);
         if (vm) {
+          if (a.wave_log) dbg_steals++;
           const int ni = (int)__popcll(im), nv = (int)__popcll(vm);
           const int n = ni < nv ? ni : nv;
           const int ir = (int)lane_rank(im), vr = (int)lane_rank(vm);
@@ -399,6 +402,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
     w[3] = rr | ((unsigned long long)dbg_inner_lanes << 32);
     w[4] = dbg_leaf_lanes | ((unsigned long long)dbg_leaf_rounds << 32);
     w[5] = dbg_busy_lanes;
+    w[6] = dbg_refills | ((unsigned long long)dbg_steals << 32);
   }
 }
 

@@ -200,23 +200,17 @@ struct ShadeOut {
 // is still alive returns true ("deferred") and touches nothing.  PASS 2: the deferred paths, regrouped
 // densely by the caller.  Bounce rays mostly leave the scene (90 % on C2), so without the regrouping
 // every wave ran the ~700-instruction surface code for a handful of its lanes.
-template <int INTEG, bool FULLCTR, int PASS, int STAGE>
-EZD bool shade_path(const WfArgs& a, const uint32_t i, bool live, Counters& ctr, uint32_t& n_samples, ShadeOut& o) {
-  constexpr bool P5TRI = (INTEG >= 50);
+struct ShadeIn { // what stage b reads for one path (from the queues, or from registers in tail_kernel)
+  float4 rd4, ro4, s0, s1, s2, s3, s4;
+  int2 h, sh;
+};
+template <int INTEG, int PASS, int STAGE>
+EZD void shade_load(const WfArgs& a, const uint32_t i, const bool live, ShadeIn& in) {
   constexpr bool MIS = (INTEG == EZRT_INTEGRATOR_P5_MIS);
-  const DevScene& sc = a.sc;
-  const EzrtRenderParams& p = a.p;
-  const int b = a.bounce;
   constexpr bool B0 = (STAGE == 0);
   constexpr bool COMPACT = compact_state<INTEG>();
-  uint32_t sslot = 0, seed = 0, flags = 0, tri0 = 0;
-  f3 history = mk(1, 1, 1), Lo = mk(0, 0, 0), Le0 = mk(0, 0, 0), f_r = mk(0, 0, 0), shadowC = mk(0, 0, 0);
-  float cosine = 0.0f, pdf = 1.0f;
-  f3 rayL = mk(0, 0, 0), shadowL = mk(0, 0, 0);
-  Hit hit;
-  hit.P = mk(0, 0, 0);
-  o.emit = false;
-
+  const EzrtRenderParams& p = a.p;
+  const int b = a.bounce;
   // first-level loads: addresses depend on i only, so issue them all up front (one memory
   // round trip) instead of discovering them one branch at a time
   const uint32_t ii = live ? i : 0u;
@@ -255,6 +249,37 @@ EZD bool shade_path(const WfArgs& a, const uint32_t i, bool live, Counters& ctr,
     }
   }
 #undef EZ_PIN4
+  in.rd4 = rd4;
+  in.ro4 = ro4;
+  in.s0 = s0;
+  in.s1 = s1;
+  in.s2 = s2;
+  in.s3 = s3;
+  in.s4 = s4;
+  in.h = h;
+  in.sh = sh;
+}
+
+// `i` is only used by stage 0 (queue position -> sample slot)
+template <int INTEG, bool FULLCTR, int PASS, int STAGE>
+EZD bool shade_body(const WfArgs& a, const uint32_t i, bool live, const ShadeIn& in, Counters& ctr, uint32_t& n_samples,
+                    ShadeOut& o) {
+  constexpr bool P5TRI = (INTEG >= 50);
+  constexpr bool MIS = (INTEG == EZRT_INTEGRATOR_P5_MIS);
+  const DevScene& sc = a.sc;
+  const EzrtRenderParams& p = a.p;
+  const int b = a.bounce;
+  constexpr bool B0 = (STAGE == 0);
+  constexpr bool COMPACT = compact_state<INTEG>();
+  uint32_t sslot = 0, seed = 0, flags = 0, tri0 = 0;
+  f3 history = mk(1, 1, 1), Lo = mk(0, 0, 0), Le0 = mk(0, 0, 0), f_r = mk(0, 0, 0), shadowC = mk(0, 0, 0);
+  float cosine = 0.0f, pdf = 1.0f;
+  f3 rayL = mk(0, 0, 0), shadowL = mk(0, 0, 0);
+  Hit hit;
+  hit.P = mk(0, 0, 0);
+  o.emit = false;
+  const float4 rd4 = in.rd4, ro4 = in.ro4, s0 = in.s0, s1 = in.s1, s2 = in.s2, s3 = in.s3, s4 = in.s4;
+  const int2 h = in.h, sh = in.sh;
   bool done = false;
   if (!live) return false;
   f3 colour = mk(0, 0, 0);
@@ -439,6 +464,12 @@ EZD bool shade_path(const WfArgs& a, const uint32_t i, bool live, Counters& ctr,
   o.pdf = pdf;
   return false;
 }
+template <int INTEG, bool FULLCTR, int PASS, int STAGE>
+EZD bool shade_path(const WfArgs& a, const uint32_t i, bool live, Counters& ctr, uint32_t& n_samples, ShadeOut& o) {
+  ShadeIn in;
+  shade_load<INTEG, PASS, STAGE>(a, i, live, in);
+  return shade_body<INTEG, FULLCTR, PASS, STAGE>(a, i, live, in, ctr, n_samples, o);
+}
 
 // FORM: 0 = the general state, 1 = compact state into stage 1, 2 = compact state into stages >= 2 (see PathState)
 template <bool MIS, int FORM>
@@ -611,6 +642,87 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_kernel(WfArgs a) {
       atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_ENV_CACHE], v6);
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// tail_kernel: everything after stage `a.bounce` for the paths of its queue, one lane per path.
+//
+// After two or three stages only a few per cent of the paths are alive (C2: 0.7 M of 16.8 M enter stage 2), and
+// a stage then costs its fixed price -- four dependent launches, each draining the chip, and persistent trace
+// waves that issue full-width instructions for a handful of live lanes -- not its work: stages 2-4 were 17 % of
+// a C2 step for 4 % of its rays.  Here a lane keeps its path in registers and alternates hitBVH (in the
+// reference's visit order: hit_bvh of ezrt_device.h, so there are no ties to redo) with the stage's shading
+// (shade_body, the same code the staged kernels run) until the path ends.  Same arithmetic per path, so the same
+// samples; ray counts are added to the same counters.
+template <int INTEG>
+__global__ __launch_bounds__(BLOCK) void tail_kernel(WfArgs a, int32_t stack_entries) {
+  extern __shared__ __attribute__((aligned(16))) int lds_stack[];
+  constexpr bool MIS = (INTEG == EZRT_INTEGRATOR_P5_MIS);
+  constexpr bool COMPACT = compact_state<INTEG>();
+  (void)stack_entries;
+  const DevScene& sc = a.sc;
+  const uint32_t n_in = *a.n_in;
+  int* stack = lds_stack + threadIdx.x;
+  Counters ctr = {0, 0, 0, 0, 0, 0, 0};
+  uint32_t n_samples = 0;
+  const int b0 = a.bounce;
+  for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_in; i += gridDim.x * BLOCK) {
+    // the path as the stage-b0 kernels would read it, except that its rays have not been traced yet
+    ShadeIn in;
+    const uint32_t rslot = MIS ? 2u * i + 1u : i;
+    in.rd4 = a.rq_in.d[rslot];
+    in.ro4 = a.rq_in.o[rslot];
+    in.s0 = a.st_in.s0[i];
+    in.s1 = a.st_in.s1[i];
+    in.s2 = a.st_in.s2[i];
+    in.s3 = COMPACT ? make_float4(0, 0, 0, 0) : a.st_in.s3[i];
+    in.s4 = make_float4(0, 0, 0, 0);
+    float4 sd4 = make_float4(0, 0, 0, 0); // shadow ray (MIS)
+    if (MIS) {
+      in.s4 = a.st_in.s4[i];
+      sd4 = a.rq_in.d[2u * i];
+    }
+    WfArgs w = a;
+    for (int b = b0;; b++) {
+      const f3 O = mk(in.ro4.x, in.ro4.y, in.ro4.z);
+      in.h = make_int2(-1, 0);
+      in.sh = make_int2(-1, 0);
+      if (MIS && sd4.w != 0.0f) {
+        int32_t tri;
+        float t;
+        hit_bvh<false, BLOCK>(sc, O, mk(sd4.x, sd4.y, sd4.z), stack, tri, t, ctr);
+        in.sh = make_int2(tri, __float_as_int(t));
+      }
+      if (in.rd4.w != 0.0f) {
+        int32_t tri;
+        float t;
+        hit_bvh<false, BLOCK>(sc, O, mk(in.rd4.x, in.rd4.y, in.rd4.z), stack, tri, t, ctr);
+        in.h = make_int2(tri, __float_as_int(t));
+      }
+      w.bounce = b;
+      ShadeOut o;
+      shade_body<INTEG, false, 0, 2>(w, i, true, in, ctr, n_samples, o);
+      if (!o.emit) break;
+      // what shade_store would have queued for stage b + 1
+      const bool shoot = !(o.flags & FLAG_TERMINATE);
+      in.ro4 = make_float4(o.P.x, o.P.y, o.P.z, 0.0f);
+      in.rd4 = make_float4(o.rayL.x, o.rayL.y, o.rayL.z, (!MIS || shoot) ? 1.0f : 0.0f);
+      if (MIS) sd4 = make_float4(o.shadowL.x, o.shadowL.y, o.shadowL.z, (o.flags & FLAG_SHADOW_SHOT) ? 1.0f : 0.0f);
+      if (COMPACT) {
+        in.s0 = make_float4(o.history.x, o.history.y, o.history.z, o.cosine);
+        in.s1 = make_float4(o.Lo.x, o.Lo.y, o.Lo.z, __uint_as_float(o.sslot));
+        in.s2 = make_float4(o.f_r.x, o.f_r.y, o.f_r.z, __uint_as_float(o.tri0));
+      } else {
+        in.s0 = make_float4(o.history.x, o.history.y, o.history.z, o.cosine);
+        in.s1 = make_float4(o.Lo.x, o.Lo.y, o.Lo.z, o.pdf);
+        in.s2 = make_float4(o.f_r.x, o.f_r.y, o.f_r.z, __uint_as_float(o.sslot));
+        in.s3 = make_float4(o.Le0.x, o.Le0.y, o.Le0.z, __uint_as_float(o.seed));
+        in.s4 = make_float4(o.shadowC.x, o.shadowC.y, o.shadowC.z, __uint_as_float(o.flags));
+      }
+    }
+  }
+  const unsigned long long rr = wave_sum(ctr.rays);
+  if ((threadIdx.x & 63) == 0 && rr) atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_RAYS], rr);
 }
 
 // ---------------------------------------------------------------------------

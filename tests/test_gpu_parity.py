@@ -263,13 +263,43 @@ def test_schedule_knobs_never_change_results(hip, bunny_small):
                      {"trace_wps": 5}, {"trace_wps": 8}, {"lds_nodes": 0}, {"lds_nodes": 7}, {"steal": 0},
                      {"scatter": 0}, {"scatter": 5}, {"scatter": 8}, {"static_pct": 0}, {"static_pct": 90},
                      {"refill_min": 1}, {"refill_min": 64}, {"split_shade": 0}, {"split_shade": 1}, {"pipes": 2},
-                     {"pipes": 2, "sub_frames": 1}, {"rel_boxes": 0}):
+                     {"pipes": 2, "sub_frames": 1}, {"rel_boxes": 0}, {"wide4": 0}, {"wide4": 0, "steal": 0},
+                     {"wide4": 0, "rel_boxes": 0}, {"tail_stage": 2}, {"tail_stage": 3, "wide4": 0}, {"refill_min": 16}):
             s2 = bunny_small.upload(hip)
             for k, v in opts.items():
                 s2.set_option(k, v)
             assert np.array_equal(_bits(s2.render(p)), _bits(ref)), (integ, opts)
     with pytest.raises(trace.TraceError, match="unknown option"):
         sg.set_option("no_such_knob", 1)
+    # values that would hang or corrupt a launch are refused: the documented ranges
+    for k, v in (("pool_max", 0), ("pool_div", 0), ("lds_nodes", -1), ("packet_budget", 0), ("leaf_threshold", 0),
+                 ("leaf_threshold", 65), ("trace_wps", 0), ("tail_stage", -1)):
+        with pytest.raises(trace.TraceError, match="outside"):
+            sg.set_option(k, v)
+
+
+def test_boxes_that_are_not_nested_fall_back_to_the_binary_kernel(hip, oracle, bunny_small):
+    """traceq4_kernel tests descendants without their ancestors, which is only the reference's traversal when
+    every box lies inside its parent's (true for the builders' trees).  Caller arrays that violate it -- here
+    some inner boxes shrunk so that their children stick out -- must still give the reference's answer."""
+    nodes = bunny_small.nodes.copy()
+    rng = np.random.default_rng(5)
+    inner = np.nonzero(nodes[2:, 3] == 0)[0] + 2
+    pick = rng.choice(inner, 60, replace=False)
+    c = (nodes[pick, 6:9] + nodes[pick, 9:12]) * np.float32(0.5)
+    nodes[pick, 6:9] = c + (nodes[pick, 6:9] - c) * np.float32(0.6)
+    nodes[pick, 9:12] = c + (nodes[pick, 9:12] - c) * np.float32(0.6)
+    sg, so = hip.scene_create(bunny_small.tri, nodes), oracle.scene_create(bunny_small.tri, nodes)
+    hdr = scenes.synthetic_hdr(64, 32)
+    sg.set_env(hdr, None, 1)
+    so.set_env(hdr, None, 1)
+    eye, cam = S.camera(10, 5, 3)
+    p = trace.make_params(160, 120, eye, cam, 50, 3, spp=2)
+    assert np.array_equal(_bits(sg.render(p)), _bits(so.render(p)))
+    sg.set_option("audit_via_queue", 1)
+    tg, dg, _ = sg.render_paths(trace.make_params(160, 120, eye, cam, 50, 3, frame0=1))
+    to, do, _ = so.render_paths(trace.make_params(160, 120, eye, cam, 50, 3, frame0=1))
+    assert np.array_equal(tg, to) and np.array_equal(_bits(dg), _bits(do))
 
 
 def test_deep_skewed_tree_uses_many_stack_rows(hip, oracle):
