@@ -1,33 +1,42 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json's metric on its config: Mrays/s at fixed spp.
+"""bench.py -- BASELINE.json's metric: Mrays/s at fixed spp.
 
-Workload (config.workload "C2"): the P3 scene with the Stanford Bunny subdivided to ~70k triangles
-(79 820 total), SAH BVH leaf 8, 512x512, integrator 50 (P5 pathTracing: Sobol + Cranley-Patterson
-hemisphere sampling, Disney BRDF), 4 bounces, 64 spp, procedural 1024x512 env map.  One "step" =
-one full render of that frame (64 spp) through libezrt_hip.so; scene, env map and the frame buffer
-are resident in HBM before the timed region.  ray := one hitBVH call, counted by the kernels.
+N = 1 (the headline line): workload C2 = BASELINE.json configs[1] made concrete as SURVEY.md 8(d): the P3 scene with
+the Stanford Bunny subdivided to ~70k triangles (79 820 total), SAH BVH leaf 8, 512x512, reference camera (r = 4),
+integrator 50 (P5 pathTracing: Sobol + Cranley-Patterson hemisphere sampling, Disney BRDF), 4 bounces, 64 spp, env
+map = the reference's only shipped HDR (P4/HDR/peppermint_powerplant_4k.hdr, 1024x512, bilinear).  One "step" = one
+full render of that frame (64 spp) through libezrt_hip.so; scene, env map and the frame buffer are resident in HBM
+before the timed region.  ray := one hitBVH call, counted by the kernels.
 
-N > 1: one process per GPU (torchrun); the image is split into 16x16 tiles dealt round-robin to the
-ranks (scene replicated), each rank traces its tiles, then ONE gather of the packed tiles to rank 0
-over RCCL closes the frame.  Default "scaling": "weak": at N GPUs the frame is rendered at 64 x N spp,
-so every GPU keeps the 1-GPU number of pixel-samples (16.8 M) on its 1/N of the tiles; `--scaling strong`
-splits the 64-spp frame N ways instead (the late bounces are latency-bound and do not shrink with
-the ray count, so strong scaling of a 5 ms frame is poor by construction -- DESIGN.md section 7).
+N > 1 (one process per GPU, torchrun): workload C4 = BASELINE.json configs[3], the config BASELINE names for 8 GPUs:
+the P5 scene (Bunny with the teapot's material, near-mirror floor), P5 preset camera (rot 90, up 10, r 2), integrator
+51 (env importance sampling + MIS), 2 bounces, 1024x1024, 256 spp -- a FIXED frame split into 16x16 tiles dealt
+round-robin to the ranks ("scaling": "strong"); the scene is replicated, every rank traces all spp of its tiles and
+ONE gather of the packed tiles to rank 0 over RCCL closes the frame.  Extra fields report per-rank render times, the
+gather time, the imbalance, the same frame rendered by rank 0 alone (so the line carries its own 1-GPU reference),
+and the weak-scaling variant (spp x N).  `--workload c2|c4` overrides the choice for any N.
 
-Prints one JSON line on rank 0 (contract in the task statement) with `roofline` and, at N = 1,
-`cpu_baseline` (the CPU oracle timed on a bounded sample of the same workload).
+Prints one JSON line on rank 0 (contract in the task statement) with `roofline` and, at N = 1, `cpu_baseline`
+(the CPU oracle timed on a bounded sample of the same workload).
 """
 import argparse
 import ctypes
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+L2_PEAK_GBS = 34500.0        # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
+LDS_PEAK_GBS = 150000.0      # MI355X_MICROARCH.md "LDS": ~150 TB/s for ds_read_b64/b128 with every CU streaming
+# VALU issue ceiling: tools/exp_valu_issue.hip on this chip (profiles/r2/valu_issue_microbench.txt): wave64 fp32
+# add/mul/mov and the slab test's own opcode mix issue at 1.0-1.09 T wave-instructions/s chip-wide (~2 cycles per
+# instruction per SIMD at the ~2.1-2.4 GHz the chip sustains), fma/min3/cndmask alone at 0.58 T.
+VALU_ISSUE_PEAK_T = 1.086
 
 
 def alg_bytes(c, bilinear=True):
@@ -38,22 +47,71 @@ def alg_bytes(c, bilinear=True):
             + 32 * c["samples"] + tex * (c["env_map"] + c["env_cache"]))
 
 
+def host_cores():
+    cores = os.cpu_count() or 1
+    try:  # a container's CPU quota (cgroup v2) is what the oracle really gets
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def physical_roofline(trace_ms_per_step, launches_per_step):
+    """Counters of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r2/pmc_summary.json, made by
+    tools/profile.sh + tools/summarize_profile.py), combined with THIS run's launch durations.  The profile is stamped
+    with a hash of the GPU sources; a stale stamp means the counters describe other code and nothing is quoted."""
+    path = os.path.join(ROOT, "profiles", "r2", "pmc_summary.json")
+    if not os.path.exists(path):
+        return None, "no profiles/r2/pmc_summary.json"
+    from ezrt_amd.srchash import gpu_source_hash
+    pm = json.load(open(path))
+    if pm.get("source_sha") != gpu_source_hash():
+        return None, "profiles/r2/pmc_summary.json is stale (GPU sources changed since it was collected)"
+    k = pm["dominant"]                      # per STEP sums over the dominant kernel's launches
+    secs = trace_ms_per_step * 1e-3
+    insts = k["SQ_INSTS_VALU"]
+    out = {
+        "kernel_instances": k["names"],
+        "valu_wave_instr_per_step": int(insts),
+        "issue_rate_T": round(insts / secs / 1e12, 4),
+        "issue_frac": round(insts / secs / 1e12 / VALU_ISSUE_PEAK_T, 4),
+        "lane_fill": round(k["SQ_THREAD_CYCLES_VALU"] / (64.0 * insts), 4),
+        "salu_per_valu": round(k["SQ_INSTS_SALU"] / insts, 3),
+        "wave_cycles_waiting": round(k["SQ_WAIT_ANY"] / k["SQ_WAVE_CYCLES"], 3),
+        "lds_conflict_frac": round(k["SQ_LDS_BANK_CONFLICT"] / max(1.0, k["SQ_ACTIVE_INST_LDS"]), 3),
+        "hbm_bytes_per_step": int(k["hbm_bytes"]),
+        "hbm_frac": round(k["hbm_bytes"] / secs / 1e9 / HBM_PEAK_GBS, 4),
+        "l2_bytes_per_step": int(k["l2_bytes"]),
+        "l2_frac": round(k["l2_bytes"] / secs / 1e9 / L2_PEAK_GBS, 4),
+        "lds_bytes_per_step": int(k["lds_bytes"]),
+        "lds_frac": round(k["lds_bytes"] / secs / 1e9 / LDS_PEAK_GBS, 4),
+        "source": "profiles/r2/pmc_summary.json @ %s" % pm["source_sha"],
+    }
+    out["traffic_per_launch"] = int(k["hbm_bytes"] / max(1, launches_per_step))
+    return out, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--width", type=int, default=512)
-    ap.add_argument("--height", type=int, default=512)
-    ap.add_argument("--spp", type=int, default=64)
-    ap.add_argument("--bounces", type=int, default=4)
-    ap.add_argument("--integrator", type=int, default=50)
+    ap.add_argument("--workload", choices=("auto", "c2", "c4"), default="auto", help="auto: C2 at 1 GPU, C4 at N > 1")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--spp", type=int, default=0)
+    ap.add_argument("--bounces", type=int, default=-1)
+    ap.add_argument("--integrator", type=int, default=0)
     ap.add_argument("--subdiv", type=int, default=2)
     ap.add_argument("--tile", type=int, default=16)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak: every GPU keeps the 1-GPU number of pixel-samples (spp x n_gpus on 1/n of the "
-                         "tiles); strong: the 1-GPU frame is split n ways")
+    ap.add_argument("--env", choices=("shipped", "synthetic"), default="shipped")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1 -- strong (default): the fixed frame is split N ways; weak: spp x N, so every GPU keeps the "
+                         "1-GPU number of pixel-samples")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time (0 = skip)")
+    ap.add_argument("--extras", type=int, default=1, help="0: skip the extra fields (second camera, 1-GPU reference, weak variant)")
     ap.add_argument("--save-png", default="")
     args = ap.parse_args()
 
@@ -86,24 +144,51 @@ def main():
     from ezrt_amd import scene as S, scenes, tiles, trace
     hip = trace.hip()  # after torch: shares torch's HIP runtime (same soname)
 
+    wl = args.workload if args.workload != "auto" else ("c2" if world == 1 else "c4")
+    cfg = dict(scenes.CONFIGS["C2" if wl == "c2" else "C4"])
+    for k_arg, k_cfg in (("width", "width"), ("height", "height"), ("spp", "spp"), ("integrator", "integrator")):
+        if getattr(args, k_arg):
+            cfg[k_cfg] = getattr(args, k_arg)
+    if args.bounces >= 0:
+        cfg["max_bounce"] = args.bounces
     t_build = time.perf_counter()
-    want_cache = args.integrator == 51
-    bs = scenes.bunny_scene(subdiv=args.subdiv, want_cache=want_cache)
+    if wl == "c2":
+        bs = scenes.bunny_scene(subdiv=args.subdiv, want_cache=(cfg["integrator"] == 51), hdr=args.env)
+        desc = "C2: P3 scene, Stanford Bunny subdivided x%d" % args.subdiv
+    else:
+        bs = scenes.p5_scene(subdiv=args.subdiv, hdr=args.env)
+        desc = "C4: P5 scene (Bunny subdivided x%d with the teapot's material, mirror floor)" % args.subdiv
     t_build = time.perf_counter() - t_build
     sc = bs.upload(hip)
-    eye, cam = S.camera(0, 0, 4)
-    W, H = args.width, args.height
-    spp = args.spp * world if args.scaling == "weak" else args.spp
-    p = trace.make_params(W, H, eye, cam, args.integrator, args.bounces, spp=spp, tile=(args.tile, args.tile),
-                          shard=(rank, world))
+    eye, cam = S.camera(*cfg["camera"])
+    W, H, integ, mb = cfg["width"], cfg["height"], cfg["integrator"], cfg["max_bounce"]
+    weak = world > 1 and args.scaling == "weak"
+    spp = cfg["spp"] * world if weak else cfg["spp"]
+    env_name = ("the reference's shipped P4/HDR/peppermint_powerplant_4k.hdr 1024x512 (asset copy), bilinear"
+                if args.env == "shipped" else "procedural 1024x512 env, bilinear")
+
+    def params(shard, n_spp=None, camera=None):
+        e, c = (eye, cam) if camera is None else S.camera(*camera)
+        return trace.make_params(W, H, e, c, integ, mb, spp=spp if n_spp is None else n_spp, tile=(args.tile, args.tile),
+                                 shard=shard)
+
+    p = params((rank, world))
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     plan = tiles.TilePlan(W, H, args.tile, args.tile, world) if world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
+    gather_s = []
 
     def step():
         sc.render_device(p, accum.data_ptr(), stream)
         if world > 1:
-            return tiles.gather_frame(accum, plan, rank, dist, via_cpu=(backend != "nccl"))
+            if rank == 0:
+                torch.cuda.synchronize()
+                tg = time.perf_counter()
+            out_img = tiles.gather_frame(accum, plan, rank, dist, via_cpu=(backend != "nccl"))
+            if rank == 0:
+                torch.cuda.synchronize()
+                gather_s.append(time.perf_counter() - tg)   # includes waiting for the slowest rank
+            return out_img
         return accum
 
     def barrier():
@@ -114,25 +199,36 @@ def main():
         step()
     torch.cuda.synchronize()
     sc.counters_reset()
-    trace_ms = []
+    gather_s.clear()
+    step_ms = []
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         final = step()
-        if world == 1:
-            trace_ms.append(sc.last_render_ms())
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    # per-step GPU times (hipEvents on the launch stream; reading them synchronises, so this is a separate, untimed
+    # pass of the same step): median of 7 -- (all kernels, the trace launches, number of trace launches)
+    rays_timed = sc.counters()["rays"]
+    for _ in range(7):
+        sc.render_device(p, accum.data_ptr(), stream)
+        step_ms.append(sc.last_render_ms())
 
-    rays_local = sc.counters()["rays"]
-    tt = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    rays_local = rays_timed
+    tdev = dev if backend == "nccl" else "cpu"
+    tt = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=tdev)
+    rank_ms = torch.tensor([statistics.median(m[0] for m in step_ms)], dtype=torch.float64, device=tdev)
+    all_rank_ms = [float(rank_ms[0])]
     if world > 1:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
+        bufs = [torch.zeros_like(rank_ms) for _ in range(world)]
+        dist.all_gather(bufs, rank_ms)
+        all_rank_ms = [float(b[0]) for b in bufs]
     rays_total = float(tt[1])
     rays_per_step = rays_total / max(1, args.steps)
     value = rays_total / elapsed / 1e6
@@ -141,96 +237,135 @@ def main():
         "metric": "Mrays/s at fixed spp (Bunny ~70k tris, 4 bounces)",
         "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 4), "higher_is_better": True,
-        "scaling": args.scaling if world > 1 else "weak",
+        "scaling": "weak" if (weak or world == 1) else "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "C2: P3 scene, Stanford Bunny subdivided x%d (%d tris, %d BVH nodes, SAH leaf 8), "
-                               "%dx%d, integrator %d, %d bounces, %d spp%s, procedural 1024x512 env"
-                               % (args.subdiv, bs.tri.shape[0], bs.nodes.shape[0], W, H, args.integrator, args.bounces,
-                                  spp, (" (= %d spp x %d GPUs: per-GPU pixel-samples fixed)" % (args.spp, world))
-                                  if (world > 1 and args.scaling == "weak") else ""),
+        "config": {"workload": "%s (%d tris, %d BVH nodes, SAH leaf 8), %dx%d, camera rot %g up %g r %g, integrator %d, %d bounces, "
+                               "%d spp%s, env = %s"
+                               % (desc, bs.tri.shape[0], bs.nodes.shape[0], W, H, cfg["camera"][0], cfg["camera"][1], cfg["camera"][2],
+                                  integ, mb, spp, (" (= %d spp x %d GPUs: per-GPU pixel-samples fixed)" % (cfg["spp"], world)) if weak else "",
+                                  env_name),
                    "rays_per_step": int(rays_per_step), "ray_definition": "one hitBVH call",
                    "parallelism": "tiles%dx%d round-robin over %d GPU(s), 1 RCCL gather/frame" % (args.tile, args.tile, world),
-                   "scene_build_s": round(t_build, 3)},
+                   "scene_build_s": round(t_build, 3),
+                   "median_gpu_ms_per_step": round(statistics.median(m[0] for m in step_ms), 4)},
     }
 
+    if world > 1:
+        # ---- what the N-GPU frame cost where (rank 0 prints; every rank takes part in the collectives above)
+        mg = {"tiles_total": plan.n_tiles, "tiles_per_rank": [len(range(r, plan.n_tiles, world)) for r in range(world)],
+              "render_ms_per_rank_median": [round(x, 4) for x in all_rank_ms],
+              "imbalance_max_over_mean": round(max(all_rank_ms) / (sum(all_rank_ms) / world), 4),
+              "payload_bytes_per_peer": plan.per_rank * args.tile * args.tile * 16}
+        if rank == 0 and gather_s:
+            mg["gather_ms_median_incl_wait_for_slowest_rank"] = round(statistics.median(gather_s) * 1e3, 4)
+        if args.extras:
+            # the same frame by rank 0 alone (the others wait at the barrier): the line's own 1-GPU reference
+            barrier()
+            if rank == 0:
+                one = torch.zeros_like(accum)
+                p1 = params((0, 1))
+                sc.counters_reset()
+                sc.render_device(p1, one.data_ptr(), stream)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                sc.render_device(p1, one.data_ptr(), stream)
+                torch.cuda.synchronize()
+                d1 = time.perf_counter() - t1
+                r1 = sc.counters()["rays"] / 2
+                mg["one_gpu_same_frame"] = {"ms": round(d1 * 1e3, 3), "Mrays_s": round(r1 / d1 / 1e6, 2),
+                                            "speedup_of_this_line": round((elapsed / args.steps) and d1 / (elapsed / args.steps), 3),
+                                            "linf_vs_n_gpu_frame": float((one - final).abs().max()) if not weak else None}
+            barrier()
+        out["multi_gpu"] = mg
+
     if rank == 0 and world == 1:
-        # ---- roofline of the dominant kernel (trace_kernel): algorithmic bytes / launch duration
+        # ---- roofline of the dominant kernel
         sc.set_instrumentation(1)
         sc.counters_reset()
         sc.render_device(p, accum.data_ptr(), stream)
         torch.cuda.synchronize()
         c = sc.counters()
-        _, _, n_launch = sc.last_render_ms()
         sc.set_instrumentation(0)
-        # Dominant kernel = traceq_kernel (persistent hitBVH over a ray queue, 1 + max_bounce launches
-        # per step).  Its algorithmic bytes are the traversal terms 48 P + 96 I + 72 T + 72 M; the
-        # remaining terms (32 B/sample, env texels) belong to the shade/accumulate kernels and are
-        # reported with the whole-step figure.
+        # Dominant kernel = the persistent hitBVH over a ray queue (traceq4_kernel; 1 + max_bounce launches per step
+        # + as many normally-empty redo launches of the in-order kernel).
         bytes_trace = 48 * c["node_pops"] + 96 * c["inner_pops"] + 72 * c["tri_tests"] + 72 * c["mat_fetch"]
         bytes_step = alg_bytes(c, bilinear=(bs.env_filter == 1))
-        ms_total = sum(m[0] for m in trace_ms) / len(trace_ms)      # all kernels of a step (hipEvents)
-        ms_trace = sum(m[1] for m in trace_ms) / len(trace_ms)      # traceq launches of a step
-        launches = max(1, trace_ms[0][2])
+        ms_total = statistics.median(m[0] for m in step_ms)       # all kernels of a step (hipEvents)
+        ms_trace = statistics.median(m[1] for m in step_ms)       # trace launches of a step (hipEvents around each)
+        launches = max(1, step_ms[0][2])
         ach = bytes_trace / (ms_trace * 1e-3) / 1e9
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "latest_pmc.json")
-        if os.path.exists(pmc_path):
-            try:
-                pm = json.load(open(pmc_path))
-                traffic = pm["traceq_hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
-        out["roofline"] = {
-            "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-            "kernel": "ezd::traceq_kernel<false,6>",
+        phys, why = physical_roofline(ms_trace, launches)
+        rf = {"kernel": "ezd::traceq4_kernel<6,*> (persistent hitBVH over a ray queue; + redo launches of ezd::traceq_kernel<false,6>)",
+              "launch_ms": round(ms_trace / launches, 4), "launches_per_step": launches, "trace_ms_per_step": round(ms_trace, 4)}
+        if phys:
+            fr = {"valu_issue": phys["issue_frac"], "hbm": phys["hbm_frac"], "l2": phys["l2_frac"], "lds": phys["lds_frac"]}
+            bound = max(fr, key=fr.get)
+            rf.update({"bound": bound, "achieved": phys["issue_rate_T"] if bound == "valu_issue" else None,
+                       "peak": VALU_ISSUE_PEAK_T, "unit": "T wave-instr/s", "frac": fr[bound],
+                       "traffic": phys["traffic_per_launch"], "ceilings": fr, "physical": phys})
+        else:
+            rf.update({"bound": "valu_issue", "achieved": None, "peak": VALU_ISSUE_PEAK_T, "unit": "T wave-instr/s", "frac": None,
+                       "traffic": None, "note_profile": why})
+        rf["work_rate_vs_hbm"] = {
+            "definition": "SURVEY.md 8(d): algorithmic bytes of the reference's unpruned traversal in the reference's record sizes "
+                          "(48 P + 96 I + 72 T + 72 M) / trace time / 8 TB/s.  A WORK-RATE figure, not a roofline: the device layout "
+                          "moves fewer bytes and the scene is cache-resident, so it can exceed 1.",
+            "achieved_GBs": round(ach, 2), "peak_GBs": HBM_PEAK_GBS, "ratio": round(ach / HBM_PEAK_GBS, 4),
+            "ratio_vs_measured_copy_peak_6290": round(ach / 6290.0, 4),
             "alg_bytes_per_launch": int(bytes_trace // launches), "alg_bytes_per_ray": round(bytes_trace / c["rays"], 1),
-            "launch_ms": round(ms_trace / launches, 4), "launches_per_step": launches,
             "counters_per_step": {k: c[k] for k in ("rays", "node_pops", "inner_pops", "tri_tests", "mat_fetch", "samples", "env_map", "env_cache")},
-            "frac_of_measured_copy_peak_6290": round(ach / 6290.0, 5),
             "whole_step": {"alg_bytes": int(bytes_step), "gpu_ms": round(ms_total, 4),
-                           "achieved_GBs": round(bytes_step / (ms_total * 1e-3) / 1e9, 2)},
-            "note": "algorithmic bytes are defined on the reference's unpruned traversal in the reference's record "
-                    "sizes (SURVEY.md 8d); the scene is L2/Infinity-Cache resident, so measured HBM traffic is far "
-                    "below them and frac can exceed 1 -- see DESIGN.md",
-        }
+                           "achieved_GBs": round(bytes_step / (ms_total * 1e-3) / 1e9, 2)}}
+        out["roofline"] = rf
+
+        if args.extras and wl == "c2":
+            # second camera (SURVEY.md 8d "worth adding"): the Bunny-filling P5 preset, same scene and settings
+            p2 = params((0, 1), camera=scenes.CONFIGS["C4"]["camera"])
+            acc2 = torch.zeros_like(accum)
+            sc.render_device(p2, acc2.data_ptr(), stream)
+            torch.cuda.synchronize()
+            sc.counters_reset()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                sc.render_device(p2, acc2.data_ptr(), stream)
+            torch.cuda.synchronize()
+            d2 = time.perf_counter() - t1
+            out["config"]["second_camera_p5_preset"] = {"camera": "rot 90 up 10 r 2 (P5/main.cpp:796-798): the Bunny fills the frame",
+                                                        "Mrays_s": round(sc.counters()["rays"] / d2 / 1e6, 2),
+                                                        "ms_per_step": round(d2 / 5 * 1e3, 4),
+                                                        "rays_per_step": int(sc.counters()["rays"] / 5)}
+
         # ---- CPU baseline: the oracle (a port, not the reference binary) on a bounded sample
         if args.cpu_seconds > 0:
             from ezrt_amd import _abi
             opath = os.path.join(ROOT, "oracle", "libezrt_oracle.so")
             ora = trace.TraceLib(_abi.declare_trace_abi(ctypes.CDLL(opath)))
             so = bs.upload(ora)
-            cores = os.cpu_count() or 1
-            try:  # a container's CPU quota (cgroup v2) is what the oracle really gets
-                quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-                if quota != "max":
-                    cores = max(1, min(cores, int(int(quota) / int(period))))
-            except (OSError, ValueError):
-                pass
+            cores = host_cores()
             try:
                 ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
             except OSError:
                 pass
+            n_spp = cfg["spp"]
             img = np.zeros((H, W, 4), np.float32)
             t1 = time.perf_counter()
-            so.render(trace.make_params(W, H, eye, cam, args.integrator, args.bounces, spp=1), img)
+            so.render(trace.make_params(W, H, eye, cam, integ, mb, spp=1), img)
             d1 = time.perf_counter() - t1
-            n = int(max(1, min(args.spp - 1, args.cpu_seconds / max(d1, 1e-3))))
+            n = int(max(1, min(n_spp - 1, args.cpu_seconds / max(d1, 1e-3))))
             so.counters_reset()
             t1 = time.perf_counter()
-            so.render(trace.make_params(W, H, eye, cam, args.integrator, args.bounces, spp=n, frame0=1), img)
+            so.render(trace.make_params(W, H, eye, cam, integ, mb, spp=n, frame0=1), img)
             dn = time.perf_counter() - t1
             gpu_img = final.detach().cpu().numpy()
-            linf = float(np.abs(gpu_img - img).max()) if n + 1 == args.spp else None
+            linf = float(np.abs(gpu_img - img).max()) if n + 1 == n_spp else None
             # many-core hosts finish the 64-spp frame in under a second: keep sampling further frames of the
             # same workload (into a scratch image) until the sample is ~cpu_seconds of CPU work
             n_total, d_total = n, dn
-            if dn < args.cpu_seconds and n + 1 == args.spp:
+            if dn < args.cpu_seconds and n + 1 == n_spp:
                 extra = int(min(8192, (args.cpu_seconds - dn) / max(dn / n, 1e-4)))
                 if extra > 0:
                     t1 = time.perf_counter()
-                    so.render(trace.make_params(W, H, eye, cam, args.integrator, args.bounces, spp=extra, frame0=args.spp),
-                              img.copy())
+                    so.render(trace.make_params(W, H, eye, cam, integ, mb, spp=extra, frame0=n_spp), img.copy())
                     d_total += time.perf_counter() - t1
                     n_total += extra
             cr = so.counters()["rays"]
@@ -245,8 +380,7 @@ def main():
                 gomp.omp_set_num_threads(1)
                 so.counters_reset()
                 t1 = time.perf_counter()
-                so.render(trace.make_params(W, H, eye, cam, args.integrator, args.bounces, spp=1, frame0=args.spp),
-                          img.copy())
+                so.render(trace.make_params(W, H, eye, cam, integ, mb, spp=1, frame0=n_spp), img.copy())
                 d1t = time.perf_counter() - t1
                 out["cpu_baseline"]["one_thread_Mrays_s"] = round(so.counters()["rays"] / d1t / 1e6, 4)
                 gomp.omp_set_num_threads(cores)
