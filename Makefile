@@ -20,7 +20,7 @@ HOST_FLAGS = -O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-math-err
 HIP_FLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math \
             -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize -Wall -Wno-unused-function -Iinclude -Iezrt_amd/csrc/hip
 
-all: host hip oracle
+all: host hip oracle examples
 
 host: $(LIBDIR)/libezrt_scene.so
 hip: $(LIBDIR)/libezrt_hip.so
@@ -36,8 +36,22 @@ $(LIBDIR)/libezrt_hip.so: $(HIP_DEPS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIP_FLAGS) -shared -o $@ $(HIP_SRC)
 
+# Consumers of the public headers outside the libraries: chapter 5's main() ported onto the C ABI + the
+# C++ host API (g++ only: the boundary needs no HIP header), and a C11 layout check of the by-value struct.
+EXDIR = examples/bin
+examples: $(EXDIR)/p5_main_port $(EXDIR)/abi_layout_check
+$(EXDIR)/p5_main_port: examples/p5_main_port.cpp $(LIBDIR)/libezrt_scene.so $(LIBDIR)/libezrt_hip.so include/ezrt.h include/ezrt_scene.hpp
+	@mkdir -p $(EXDIR)
+	$(CXX) -O2 -std=c++17 -Wall -Wextra -Iinclude -o $@ examples/p5_main_port.cpp -L$(LIBDIR) -lezrt_scene -lezrt_hip \
+	    -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)' -Wl,-rpath,$(ROCM)/lib -Wl,-rpath-link,$(ROCM)/lib
+$(EXDIR)/abi_layout_check: examples/abi_layout_check.c $(LIBDIR)/libezrt_scene.so $(LIBDIR)/libezrt_hip.so $(wildcard include/*.h)
+	@mkdir -p $(EXDIR)
+	$(CC) -O1 -std=c11 -Wall -Wextra -pedantic -Iinclude -o $@ examples/abi_layout_check.c -L$(LIBDIR) -lezrt_scene -lezrt_hip \
+	    -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)' -Wl,-rpath,$(ROCM)/lib -Wl,-rpath-link,$(ROCM)/lib
+
 clean:
+	rm -rf $(EXDIR)
 	rm -f $(LIBDIR)/*.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all host hip oracle clean
+.PHONY: all host hip oracle examples clean

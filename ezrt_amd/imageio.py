@@ -53,3 +53,33 @@ def read_pfm(path):
         scale = float(f.readline())
         data = np.frombuffer(f.read(w * h * 12), "<f4" if scale < 0 else ">f4")
     return data.reshape(h, w, 3).astype(np.float32)
+
+
+def write_hdr_rgbe(path, rgbe):
+    """uint8 [H, W, 4] RGBE texels -> a Radiance .hdr file HDRLoader::load reads back exactly
+    (P5/lib/hdrloader.cpp:50-118).  New-style scanlines (2, 2, W_hi, W_lo, then the four channels, each
+    as literal chunks of <= 128 bytes) for 8 <= W < 32768, the flat old format otherwise."""
+    a = np.ascontiguousarray(np.asarray(rgbe, np.uint8))
+    h, w, c = a.shape
+    if c != 4:
+        raise ValueError("expected [H, W, 4] RGBE")
+    head = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w)
+    if w < 8 or w >= 32768:
+        body = a.tobytes()
+    else:
+        planes = np.transpose(a, (0, 2, 1))                      # [H, 4, W]
+        full, rest = divmod(w, 128)
+        parts = []
+        if full:
+            blk = planes[:, :, :full * 128].reshape(h, 4, full, 128)
+            cnt = np.full((h, 4, full, 1), 128, np.uint8)
+            parts.append(np.concatenate([cnt, blk], axis=3).reshape(h, 4, full * 129))
+        if rest:
+            cnt = np.full((h, 4, 1), rest, np.uint8)
+            parts.append(np.concatenate([cnt, planes[:, :, full * 128:]], axis=2))
+        chan = np.concatenate(parts, axis=2).reshape(h, -1)      # the four channels of a scanline, back to back
+        mark = np.tile(np.array([2, 2, (w >> 8) & 255, w & 255], np.uint8), (h, 1))
+        body = np.concatenate([mark, chan], axis=1).tobytes()
+    with open(path, "wb") as f:
+        f.write(head)
+        f.write(body)

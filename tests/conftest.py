@@ -21,7 +21,7 @@ def _ensure_built():
             os.path.join(ROOT, "ezrt_amd", "lib", "libezrt_hip.so"),
             os.path.join(ROOT, "oracle", "libezrt_oracle.so")]
     if not all(os.path.exists(p) for p in need):
-        subprocess.check_call(["make", "-C", ROOT, "host", "hip", "oracle"])
+        subprocess.check_call(["make", "-C", ROOT, "host", "hip", "oracle", "examples"])
 
 
 @pytest.fixture(scope="session")
