@@ -24,6 +24,7 @@ INTEGRATOR_P3_DIFFUSE = 3
 INTEGRATOR_P4_DISNEY = 4
 INTEGRATOR_P5_SOBOL = 50
 INTEGRATOR_P5_MIS = 51
+INTEGRATOR_P5_MIS_ANISO = 52  # P5's loop with the anisotropic lobe evaluated + importance-sampled
 FILTER_NEAREST = 0
 FILTER_BILINEAR = 1
 
@@ -48,6 +49,7 @@ TRACE_ABI = {
     "ezrt_scene_create": (C.c_int, [c_float_p, C.c_int, c_float_p, C.c_int, C.POINTER(C.c_void_p)]),
     "ezrt_scene_destroy": (None, [C.c_void_p]),
     "ezrt_scene_set_env": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_int, C.c_int, C.c_int]),
+    "ezrt_scene_set_sampler": (C.c_int, [C.c_void_p, C.c_int]),
     "ezrt_render": (C.c_int, [C.c_void_p, C.POINTER(EzrtRenderParams), c_float_p]),
     "ezrt_render_device": (C.c_int, [C.c_void_p, C.POINTER(EzrtRenderParams), C.c_void_p, C.c_void_p]),
     "ezrt_render_paths": (C.c_int, [C.c_void_p, C.POINTER(EzrtRenderParams), c_int32_p, c_float_p, c_float_p]),

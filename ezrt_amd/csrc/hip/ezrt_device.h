@@ -68,7 +68,14 @@ struct DevScene {
   const float4* hdr;   // RGBA texels, row 0 = top
   const float4* cache; // (x/w, y/h, pdf, 0)
   int32_t env_w, env_h, env_filter;
+  uint32_t sobol_mask; // 7: Sobol dimensions wrap d & 7 (the reference's table), 15: sixteen dimensions (ezrt_scene_set_sampler)
 };
+
+// integrators 51 and 52 share pathTracingImportanceSampling's loop (P5/fsh:810-890); 52 swaps in the anisotropic lobe
+template <int INTEG>
+constexpr bool integ_mis() { return INTEG == EZRT_INTEGRATOR_P5_MIS || INTEG == EZRT_INTEGRATOR_P5_MIS_ANISO; }
+template <int INTEG>
+constexpr bool integ_aniso_is() { return INTEG == EZRT_INTEGRATOR_P5_MIS_ANISO; }
 
 constexpr uint32_t LEAF_BIT = 0x80000000u;
 
@@ -580,6 +587,65 @@ EZD float brdf_pdf(f3 V, f3 N, f3 L, const Mat& m) {
 EZD float mis_mix_weight(float a, float b) { // P5/fsh:754-757
   float t = a * a;
   return t / (b * b + t);
+}
+
+// ---- SURVEY 8(f4), integrator 52: the anisotropic specular lobe (P4/fsh:440-449; commented out in P5/fsh:472-483)
+// importance-sampled and priced.  Not in the reference: include/ezrt.h (EZRT_INTEGRATOR_P5_MIS_ANISO) names the
+// specification (sample_gtr2_aniso, sample_brdf_aniso, brdf_pdf_aniso); these are the same operations in the same order.
+EZD void aniso_alphas(const Mat& m, float& ax, float& ay) { // P4/fsh:441-443
+  float aspect = __builtin_sqrtf(1.0f - m.anisotropic * 0.9f);
+  ax = ez_max(0.001f, sqr(m.roughness) / aspect);
+  ay = ez_max(0.001f, sqr(m.roughness) * aspect);
+}
+EZD f3 sample_gtr2_aniso(float xi1, float xi2, f3 V, f3 N, f3 X, f3 Y, float ax, float ay) {
+  float phi_h = 2.0f * PI * xi1;
+  float sin_phi_h, cos_phi_h;
+  ez_sincos(phi_h, &sin_phi_h, &cos_phi_h);
+  float k = __builtin_sqrtf(xi2 / ez_max(1e-7f, 1.0f - xi2));
+  f3 H = (X * (k * ax * cos_phi_h) + Y * (k * ay * sin_phi_h)) + N;
+  H = normalize(H);
+  return reflect(-V, H);
+}
+EZD f3 sample_brdf_aniso(float xi1, float xi2, float xi3, f3 V, f3 N, f3 X, f3 Y, const Mat& m) {
+  float alpha_GTR1 = ez_mix(0.1f, 0.001f, m.clearcoatGloss);
+  float ax, ay;
+  aniso_alphas(m, ax, ay);
+  float r_diffuse = 1.0f - m.metallic;
+  float r_specular = 1.0f;
+  float r_clearcoat = 0.25f * m.clearcoat;
+  float r_sum = r_diffuse + r_specular + r_clearcoat;
+  float p_diffuse = r_diffuse / r_sum;
+  float p_specular = r_specular / r_sum;
+  float rd = xi3;
+  if (rd <= p_diffuse) return sample_cosine_hemisphere(xi1, xi2, N);
+  if (p_diffuse < rd && rd <= p_diffuse + p_specular) return sample_gtr2_aniso(xi1, xi2, V, N, X, Y, ax, ay);
+  if (p_diffuse + p_specular < rd) {
+    float c = __builtin_sqrtf((1.0f - ez_pow(alpha_GTR1 * alpha_GTR1, 1.0f - xi2)) / (1.0f - alpha_GTR1 * alpha_GTR1));
+    return sample_gtr(xi1, V, N, c);
+  }
+  return mk(0, 1, 0);
+}
+EZD float brdf_pdf_aniso(f3 V, f3 N, f3 L, f3 X, f3 Y, const Mat& m) {
+  float NdotL = dot(N, L), NdotV = dot(N, V);
+  if (NdotL < 0.0f || NdotV < 0.0f) return 0.0f;
+  f3 H = normalize(L + V);
+  float NdotH = dot(N, H), LdotH = dot(L, H);
+  float ax, ay;
+  aniso_alphas(m, ax, ay);
+  float Ds = gtr2_aniso(NdotH, dot(H, X), dot(H, Y), ax, ay);
+  float Dr = gtr1(NdotH, ez_mix(0.1f, 0.001f, m.clearcoatGloss));
+  float pdf_diffuse = NdotL / PI;
+  float pdf_specular = Ds * NdotH / (4.0f * LdotH);
+  float pdf_clearcoat = Dr * NdotH / (4.0f * LdotH);
+  float r_diffuse = 1.0f - m.metallic;
+  float r_specular = 1.0f;
+  float r_clearcoat = 0.25f * m.clearcoat;
+  float r_sum = r_diffuse + r_specular + r_clearcoat;
+  float p_diffuse = r_diffuse / r_sum;
+  float p_specular = r_specular / r_sum;
+  float p_clearcoat = r_clearcoat / r_sum;
+  float pdf = p_diffuse * pdf_diffuse + p_specular * pdf_specular + p_clearcoat * pdf_clearcoat;
+  return ez_max(1e-10f, pdf);
 }
 
 } // namespace ezd

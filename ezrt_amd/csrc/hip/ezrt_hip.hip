@@ -167,6 +167,7 @@ struct EzrtScene {
   uint32_t root_ref = 0;
   int env_w = 0, env_h = 0, env_filter = 0;
   bool has_cache = false;
+  uint32_t sobol_mask = 7u; // ezrt_scene_set_sampler
   int instr = 0;
   int depth = 0;
   int64_t stats[6] = {0, 0, 0, 0, 0, 0};
@@ -202,6 +203,7 @@ struct EzrtScene {
     d.env_w = env_w;
     d.env_h = env_h;
     d.env_filter = env_filter;
+    d.sobol_mask = sobol_mask;
     return d;
   }
 };
@@ -232,12 +234,12 @@ int validate_params(const EzrtScene* s, const EzrtRenderParams* p) {
   if (p->x0 < 0 || p->y0 < 0 || p->x1 > p->width || p->y1 > p->height || p->x0 > p->x1 || p->y0 > p->y1)
     return fail(EZRT_ERR_INVALID, "pixel rect outside the image");
   if (p->max_bounce < 0 || p->max_bounce > 64) return fail(EZRT_ERR_INVALID, "max_bounce out of range [0,64]");
-  if (p->integrator != 3 && p->integrator != 4 && p->integrator != 50 && p->integrator != 51)
+  if (p->integrator != 3 && p->integrator != 4 && p->integrator != 50 && p->integrator != 51 && p->integrator != 52)
     return fail(EZRT_ERR_INVALID, "unknown integrator");
   if (p->shard_count < 0 || p->shard_index < 0 || (p->shard_count > 0 && p->shard_index >= p->shard_count))
     return fail(EZRT_ERR_INVALID, "bad shard index/count");
   if (p->tile_w < 0 || p->tile_h < 0) return fail(EZRT_ERR_INVALID, "bad tile size");
-  if (p->integrator == EZRT_INTEGRATOR_P5_MIS && !s->has_cache)
+  if ((p->integrator == EZRT_INTEGRATOR_P5_MIS || p->integrator == EZRT_INTEGRATOR_P5_MIS_ANISO) && !s->has_cache)
     return fail(EZRT_ERR_INVALID, "integrator 51 needs the env cache (ezrt_scene_set_env)");
   return 0;
 }
@@ -289,6 +291,7 @@ void launch_trace(const TraceArgs& a, int mode, dim3 grid, size_t lds, hipStream
     case EZRT_INTEGRATOR_P3_DIFFUSE: launch_trace_i<EZRT_INTEGRATOR_P3_DIFFUSE>(a, mode, grid, lds, st); break;
     case EZRT_INTEGRATOR_P4_DISNEY: launch_trace_i<EZRT_INTEGRATOR_P4_DISNEY>(a, mode, grid, lds, st); break;
     case EZRT_INTEGRATOR_P5_SOBOL: launch_trace_i<EZRT_INTEGRATOR_P5_SOBOL>(a, mode, grid, lds, st); break;
+    case EZRT_INTEGRATOR_P5_MIS_ANISO: launch_trace_i<EZRT_INTEGRATOR_P5_MIS_ANISO>(a, mode, grid, lds, st); break;
     default: launch_trace_i<EZRT_INTEGRATOR_P5_MIS>(a, mode, grid, lds, st); break;
   }
 }
@@ -464,6 +467,7 @@ void launch_shade_split(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hi
     case EZRT_INTEGRATOR_P3_DIFFUSE: launch_shade_split_i<EZRT_INTEGRATOR_P3_DIFFUSE>(a, full, grid, grid_hit, st); break;
     case EZRT_INTEGRATOR_P4_DISNEY: launch_shade_split_i<EZRT_INTEGRATOR_P4_DISNEY>(a, full, grid, grid_hit, st); break;
     case EZRT_INTEGRATOR_P5_SOBOL: launch_shade_split_i<EZRT_INTEGRATOR_P5_SOBOL>(a, full, grid, grid_hit, st); break;
+    case EZRT_INTEGRATOR_P5_MIS_ANISO: launch_shade_split_i<EZRT_INTEGRATOR_P5_MIS_ANISO>(a, full, grid, grid_hit, st); break;
     default: launch_shade_split_i<EZRT_INTEGRATOR_P5_MIS>(a, full, grid, grid_hit, st); break;
   }
 }
@@ -472,6 +476,7 @@ void launch_shade(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
     case EZRT_INTEGRATOR_P3_DIFFUSE: launch_shade_i<EZRT_INTEGRATOR_P3_DIFFUSE>(a, full, grid, st); break;
     case EZRT_INTEGRATOR_P4_DISNEY: launch_shade_i<EZRT_INTEGRATOR_P4_DISNEY>(a, full, grid, st); break;
     case EZRT_INTEGRATOR_P5_SOBOL: launch_shade_i<EZRT_INTEGRATOR_P5_SOBOL>(a, full, grid, st); break;
+    case EZRT_INTEGRATOR_P5_MIS_ANISO: launch_shade_i<EZRT_INTEGRATOR_P5_MIS_ANISO>(a, full, grid, st); break;
     default: launch_shade_i<EZRT_INTEGRATOR_P5_MIS>(a, full, grid, st); break;
   }
 }
@@ -483,7 +488,7 @@ struct PathLogTarget { // ezrt_render_paths through the timed pipeline (audit_vi
 };
 int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, uint32_t frame_first, uint32_t nf, hipStream_t st,
                     const PathLogTarget* plog = nullptr) {
-  const bool mis = p->integrator == EZRT_INTEGRATOR_P5_MIS;
+  const bool mis = p->integrator == EZRT_INTEGRATOR_P5_MIS || p->integrator == EZRT_INTEGRATOR_P5_MIS_ANISO;
   const bool full = s->instr > 0;
   const size_t n_slots = (size_t)nb * BLOCK * nf;
   const size_t n_rays_max = n_slots * (mis ? 2 : 1);
@@ -565,7 +570,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     while (m > 1u && gcd(m, n_sub) != 1u) m += 2u;
     a.scatter = m % n_sub ? m % n_sub : 1u;
   }
-  HIP_TRY(pp.sobol_tab.ensure((size_t)nf * 8));
+  HIP_TRY(pp.sobol_tab.ensure((size_t)nf * 16));
   a.sobol_tab = pp.sobol_tab.p;
   a.sobol_out = pp.sobol_tab.p;
   a.n_frames = nf;
@@ -606,6 +611,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
         case EZRT_INTEGRATOR_P3_DIFFUSE: hipLaunchKernelGGL((tail_kernel<EZRT_INTEGRATOR_P3_DIFFUSE>), dim3(tg), dim3(BLOCK), tl, st, a, s->depth); break;
         case EZRT_INTEGRATOR_P4_DISNEY: hipLaunchKernelGGL((tail_kernel<EZRT_INTEGRATOR_P4_DISNEY>), dim3(tg), dim3(BLOCK), tl, st, a, s->depth); break;
         case EZRT_INTEGRATOR_P5_SOBOL: hipLaunchKernelGGL((tail_kernel<EZRT_INTEGRATOR_P5_SOBOL>), dim3(tg), dim3(BLOCK), tl, st, a, s->depth); break;
+        case EZRT_INTEGRATOR_P5_MIS_ANISO: hipLaunchKernelGGL((tail_kernel<EZRT_INTEGRATOR_P5_MIS_ANISO>), dim3(tg), dim3(BLOCK), tl, st, a, s->depth); break;
         default: hipLaunchKernelGGL((tail_kernel<EZRT_INTEGRATOR_P5_MIS>), dim3(tg), dim3(BLOCK), tl, st, a, s->depth); break;
       }
       break;
@@ -1398,7 +1404,7 @@ int ezrt_tonemap(const float* rgba, int n_pixels, uint8_t* rgb8) {
 }
 
 int ezrt_sobol(uint32_t index0, int n, int n_dims, float* out) {
-  if (!out || n < 0 || n_dims < 1 || n_dims > 8) return fail(EZRT_ERR_INVALID, "bad sobol arguments");
+  if (!out || n < 0 || n_dims < 1 || n_dims > 16) return fail(EZRT_ERR_INVALID, "bad sobol arguments");
   if (n == 0) return 0;
   DevBuf<float> d;
   size_t cnt = (size_t)n * n_dims;
@@ -1406,6 +1412,12 @@ int ezrt_sobol(uint32_t index0, int n, int n_dims, float* out) {
   hipLaunchKernelGGL(sobol_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, nullptr, index0, n, n_dims, d.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, d.p, cnt * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int ezrt_scene_set_sampler(EzrtScene* s, int sobol_dims) {
+  if (!s || (sobol_dims != 8 && sobol_dims != 16)) return fail(EZRT_ERR_INVALID, "sobol_dims must be 8 or 16");
+  s->sobol_mask = (uint32_t)sobol_dims - 1u;
   return 0;
 }
 
@@ -1466,9 +1478,10 @@ int ezrt_scene_stats(EzrtScene* s, int64_t out[6]) {
 }
 
 int ezrt_debug_math(int op, const float* a, const float* b, int n, float* out) {
-  if (!a || !out || n < 0 || op < 0 || op > 12) return fail(EZRT_ERR_INVALID, "bad argument");
+  if (!a || !out || n < 0 || op < 0 || op > 16) return fail(EZRT_ERR_INVALID, "bad argument");
   if (n == 0) return 0;
-  // ops 10-12 (intersector audit): a = n rays of 6 floats, b = n boxes of 6 / triangles of 9 floats
+  // ops 10-12 (intersector audit): a = n rays of 6 floats, b = n boxes of 6 / triangles of 9 floats;
+  // ops 13-16 (integrator 52's sampler): a = n x 6, b = n x 6 material parameters
   const size_t wa = op >= 10 ? 6 : 1, wb = op == 11 ? 9 : (op >= 10 ? 6 : 1);
   if (op >= 10 && !b) return fail(EZRT_ERR_INVALID, "bad argument");
   DevBuf<float> da, db, dout;

@@ -23,8 +23,10 @@ namespace ezd {
 
 constexpr int BLOCK = 256;
 
-__constant__ uint32_t c_sobol_v[8 * 32] = {
+// dims 0-7: the shader literal (P5/fsh:351-353); dims 8-15: include/ezrt.h, ezrt_scene_set_sampler
+__constant__ uint32_t c_sobol_v[16 * 32] = {
 #include "ezrt_sobol_v.inc"
+#include "ezrt_sobol_v16.inc"
 };
 
 // sobol(d, i): P5/fsh:361-369
@@ -78,6 +80,8 @@ template <int INTEG, bool FULLCTR, bool PATHLOG>
 __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
   extern __shared__ __attribute__((aligned(16))) int lds_stack[];
   constexpr bool P5TRI = (INTEG >= 50);
+  constexpr bool MIS = integ_mis<INTEG>();
+  constexpr bool ANISO_IS = integ_aniso_is<INTEG>();
   const int tid = threadIdx.x;
   const int blk = blockIdx.x % a.n_blocks;
   const int fk = blockIdx.x / a.n_blocks;
@@ -136,7 +140,9 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 
       for (int bounce = 0; bounce < p.max_bounce; bounce++) {
         const f3 V = -hit.viewDir, N = hit.N;
-        if (INTEG == EZRT_INTEGRATOR_P5_MIS) {
+        f3 X = mk(0, 0, 0), Y = mk(0, 0, 0);
+        if (ANISO_IS) get_tangent(N, X, Y);
+        if (MIS) {
           // env importance sample + shadow ray: P5/fsh:819-842
           float h1 = rnd(seed);
           float h2 = rnd(seed);
@@ -149,8 +155,8 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
             if (st < 0) {
               f3 color = hdr_color<FULLCTR>(sc, Lh, p.env_clamp, ctr);
               float pdf_light = hdr_pdf<FULLCTR>(sc, Lh, ctr);
-              f3 f_r = brdf_evaluate<false>(V, N, Lh, mk(0, 0, 0), mk(0, 0, 0), hit.m);
-              float pdf_brdf = brdf_pdf(V, N, Lh, hit.m);
+              f3 f_r = brdf_evaluate<ANISO_IS>(V, N, Lh, X, Y, hit.m);
+              float pdf_brdf = ANISO_IS ? brdf_pdf_aniso(V, N, Lh, X, Y, hit.m) : brdf_pdf(V, N, Lh, hit.m);
               float w = mis_mix_weight(pdf_light, pdf_brdf);
               Lo = Lo + (((history * w) * color) * f_r) * dot(N, Lh) / pdf_light;
             }
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
         f3 L;
         float xi1, xi2;
         if (INTEG >= 50) { // sobolVec2 + CP: P5/fsh:771-772, 845-846 (dims wrap at 8)
-          uint32_t d0 = ((uint32_t)bounce * 2u) & 7u, d1 = ((uint32_t)bounce * 2u + 1u) & 7u;
+          uint32_t d0 = ((uint32_t)bounce * 2u) & sc.sobol_mask, d1 = ((uint32_t)bounce * 2u + 1u) & sc.sobol_mask;
           xi1 = cp_rotate(sobol(d0, gray), cpu);
           xi2 = cp_rotate(sobol(d1, gray), cpv);
         } else { // P3/fsh:109-114: z = rand() then phi = 2 pi rand()
@@ -169,9 +175,9 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
         }
         float cosine, pdf;
         f3 f_r;
-        if (INTEG == EZRT_INTEGRATOR_P5_MIS) {
+        if (MIS) {
           float xi3 = rnd(seed);
-          L = sample_brdf(xi1, xi2, xi3, V, N, hit.m);
+          L = ANISO_IS ? sample_brdf_aniso(xi1, xi2, xi3, V, N, X, Y, hit.m) : sample_brdf(xi1, xi2, xi3, V, N, hit.m);
           cosine = dot(N, L);
           if (cosine <= 0.0f) break;
         } else {
@@ -190,14 +196,14 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
         float ntt;
         hit_bvh<FULLCTR, BLOCK>(sc, hit.P, L, stack, nt, ntt, ctr);
         plog<PATHLOG>(a, pix, 2 + 2 * bounce, nt, ntt);
-        if (INTEG == EZRT_INTEGRATOR_P5_MIS) {
-          f_r = brdf_evaluate<false>(V, N, L, mk(0, 0, 0), mk(0, 0, 0), hit.m);
-          pdf = brdf_pdf(V, N, L, hit.m);
+        if (MIS) {
+          f_r = brdf_evaluate<ANISO_IS>(V, N, L, X, Y, hit.m);
+          pdf = ANISO_IS ? brdf_pdf_aniso(V, N, L, X, Y, hit.m) : brdf_pdf(V, N, L, hit.m);
           if (pdf <= 0.0f) break;
         }
         if (nt < 0) {
           f3 sky = hdr_color<FULLCTR>(sc, L, p.env_clamp, ctr);
-          if (INTEG == EZRT_INTEGRATOR_P5_MIS) {
+          if (MIS) {
             float pdf_light = hdr_pdf<FULLCTR>(sc, L, ctr);
             float w = mis_mix_weight(pdf, pdf_light);
             Lo = Lo + (((history * w) * sky) * f_r) * cosine / pdf;
@@ -376,6 +382,28 @@ __global__ void isect_kernel(int op, const float* a, const float* b, int n, floa
   if (i >= n) return;
   const float* r = a + 6 * (size_t)i;
   f3 S = mk(r[0], r[1], r[2]), d = mk(r[3], r[4], r[5]);
+  if (op >= 13) { // integrator 52's sampler / pdf in the frame N = (0,0,1) (include/ezrt.h, ezrt_debug_math)
+    const float* q = b + 6 * (size_t)i;
+    Mat m;
+    m.emissive = mk(0, 0, 0);
+    m.baseColor = mk(0, 0, 0);
+    m.subsurface = m.specular = m.specularTint = m.sheen = m.sheenTint = 0.0f;
+    m.roughness = q[0];
+    m.anisotropic = q[1];
+    m.metallic = q[2];
+    m.clearcoat = q[3];
+    m.clearcoatGloss = q[4];
+    const f3 N = mk(0, 0, 1);
+    f3 X, Y;
+    get_tangent(N, X, Y);
+    if (op == 13) {
+      out[i] = brdf_pdf_aniso(S, N, d, X, Y, m);
+    } else {
+      const f3 L = sample_brdf_aniso(r[0], r[1], r[2], d, N, X, Y, m);
+      out[i] = op == 14 ? L.x : (op == 15 ? L.y : L.z);
+    }
+    return;
+  }
   if (op == 11) {
     const float* t = b + 9 * (size_t)i;
     float e1x = t[3] - t[0], e1y = t[4] - t[1], e1z = t[5] - t[2];

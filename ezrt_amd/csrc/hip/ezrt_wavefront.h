@@ -56,7 +56,7 @@ struct WfArgs {
   const uint32_t* n_in;    // paths in the input queue (device)
   uint32_t* n_out;         // paths in the output queue (device, atomically grown)
   int32_t bounce;          // the bounce this stage starts (0 = consumes the primary hits)
-  const float* sobol_tab;  // [frame - frame_first][8]: sobol(d, grayCode(frame + 1)), filled by raygen_kernel
+  const float* sobol_tab;  // [frame - frame_first][16]: sobol(d, grayCode(frame + 1)), filled by raygen_kernel
   float* sobol_out;        // (the same table, as raygen_kernel writes it)
   uint32_t n_frames;       // frames of the chunk
   uint32_t* defer_list;    // split shading: per workgroup of shade_miss_kernel, the paths with a surface interaction
@@ -98,9 +98,9 @@ __global__ __launch_bounds__(BLOCK) void raygen_kernel(WfArgs a) {
   const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
   if (slot >= a.n_slots) return;
   if (slot == 0) *a.n_out = a.n_slots; // stage 0's path count, read by the first trace launch
-  if (blockIdx.x == 0) // the chunk's Sobol table (read by the shading stages): sobol(d, grayCode(frame + 1)), 8 dims per frame
-    for (uint32_t k = threadIdx.x; k < a.n_frames * 8u; k += BLOCK)
-      a.sobol_out[k] = sobol(k & 7u, gray_code(a.frame_first + (k >> 3) + 1u));
+  if (blockIdx.x == 0) // the chunk's Sobol table (read by the shading stages): sobol(d, grayCode(frame + 1)), 16 dims per frame
+    for (uint32_t k = threadIdx.x; k < a.n_frames * 16u; k += BLOCK)
+      a.sobol_out[k] = sobol(k & 15u, gray_code(a.frame_first + (k >> 4) + 1u));
   int x, y;
   uint32_t frame;
   slot_to_pixel(a.blocks, a.n_blocks, queue_to_sample(slot, (uint32_t)a.n_blocks, a.scatter, a.scatter_shift), a.frame_first, x, y, frame);
@@ -206,7 +206,7 @@ struct ShadeIn { // what stage b reads for one path (from the queues, or from re
 };
 template <int INTEG, int PASS, int STAGE>
 EZD void shade_load(const WfArgs& a, const uint32_t i, const bool live, ShadeIn& in) {
-  constexpr bool MIS = (INTEG == EZRT_INTEGRATOR_P5_MIS);
+  constexpr bool MIS = integ_mis<INTEG>();
   constexpr bool B0 = (STAGE == 0);
   constexpr bool COMPACT = compact_state<INTEG>();
   const EzrtRenderParams& p = a.p;
@@ -265,7 +265,7 @@ template <int INTEG, bool FULLCTR, int PASS, int STAGE>
 EZD bool shade_body(const WfArgs& a, const uint32_t i, bool live, const ShadeIn& in, Counters& ctr, uint32_t& n_samples,
                     ShadeOut& o) {
   constexpr bool P5TRI = (INTEG >= 50);
-  constexpr bool MIS = (INTEG == EZRT_INTEGRATOR_P5_MIS);
+  constexpr bool MIS = integ_mis<INTEG>();
   const DevScene& sc = a.sc;
   const EzrtRenderParams& p = a.p;
   const int b = a.bounce;
@@ -385,6 +385,9 @@ EZD bool shade_body(const WfArgs& a, const uint32_t i, bool live, const ShadeIn&
     uint32_t frame;
     slot_to_pixel(a.blocks, a.n_blocks, sslot, a.frame_first, x, y, frame);
     const f3 V = -hit.viewDir, N = hit.N;
+    constexpr bool ANISO_IS = integ_aniso_is<INTEG>();
+    f3 X = mk(0, 0, 0), Y = mk(0, 0, 0);
+    if (ANISO_IS) get_tangent(N, X, Y);
     flags = 0;
     bool shoot = true;
     if (MIS) {
@@ -398,8 +401,8 @@ EZD bool shade_body(const WfArgs& a, const uint32_t i, bool live, const ShadeIn&
         Counters dummy = {0, 0, 0, 0, 0, 0, 0};
         f3 color = hdr_color<false>(sc, Lh, p.env_clamp, dummy);
         float pdf_light = hdr_pdf<false>(sc, Lh, dummy);
-        f3 fr = brdf_evaluate<false>(V, N, Lh, mk(0, 0, 0), mk(0, 0, 0), hit.m);
-        float pdf_brdf = brdf_pdf(V, N, Lh, hit.m);
+        f3 fr = brdf_evaluate<ANISO_IS>(V, N, Lh, X, Y, hit.m);
+        float pdf_brdf = ANISO_IS ? brdf_pdf_aniso(V, N, Lh, X, Y, hit.m) : brdf_pdf(V, N, Lh, hit.m);
         float w = mis_mix_weight(pdf_light, pdf_brdf);
         shadowC = (((history * w) * color) * fr) * dot(N, Lh) / pdf_light;
       }
@@ -408,8 +411,8 @@ EZD bool shade_body(const WfArgs& a, const uint32_t i, bool live, const ShadeIn&
     if (INTEG >= 50) {
       float cpu, cpv;
       cp_offsets((uint32_t)x, (uint32_t)y, cpu, cpv);
-      const float* sob = a.sobol_tab + (size_t)(frame - a.frame_first) * 8u; // sobol(d, grayCode(frame + 1))
-      const uint32_t d0 = ((uint32_t)b * 2u) & 7u, d1 = ((uint32_t)b * 2u + 1u) & 7u;
+      const float* sob = a.sobol_tab + (size_t)(frame - a.frame_first) * 16u; // sobol(d, grayCode(frame + 1))
+      const uint32_t d0 = ((uint32_t)b * 2u) & sc.sobol_mask, d1 = ((uint32_t)b * 2u + 1u) & sc.sobol_mask;
       xi1 = cp_rotate(sob[d0], cpu);
       xi2 = cp_rotate(sob[d1], cpv);
     } else {
@@ -418,14 +421,14 @@ EZD bool shade_body(const WfArgs& a, const uint32_t i, bool live, const ShadeIn&
     }
     if (MIS) {
       float xi3 = rnd(seed);
-      rayL = sample_brdf(xi1, xi2, xi3, V, N, hit.m);
+      rayL = ANISO_IS ? sample_brdf_aniso(xi1, xi2, xi3, V, N, X, Y, hit.m) : sample_brdf(xi1, xi2, xi3, V, N, hit.m);
       cosine = dot(N, rayL);
       if (cosine <= 0.0f) {
         shoot = false;
         flags |= FLAG_TERMINATE;
       } else {
-        f_r = brdf_evaluate<false>(V, N, rayL, mk(0, 0, 0), mk(0, 0, 0), hit.m);
-        pdf = brdf_pdf(V, N, rayL, hit.m);
+        f_r = brdf_evaluate<ANISO_IS>(V, N, rayL, X, Y, hit.m);
+        pdf = ANISO_IS ? brdf_pdf_aniso(V, N, rayL, X, Y, hit.m) : brdf_pdf(V, N, rayL, hit.m);
         if (pdf <= 0.0f) flags |= FLAG_PDF_DEAD;
       }
     } else {
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_hit_kernel(WfArgs a) {
   __shared__ uint32_t alloc_lds[SHADE_BLOCK / 64 + 1];
   constexpr bool B0 = (STAGE == 0);
   constexpr int FORM = store_form<INTEG, STAGE>();
-  constexpr bool MIS = (INTEG == EZRT_INTEGRATOR_P5_MIS);
+  constexpr bool MIS = integ_mis<INTEG>();
   const uint32_t n_in = B0 ? a.n_slots : *a.n_in;
   const uint32_t stride = gridDim.x * SHADE_BLOCK;
   const uint32_t iters = (n_in + stride - 1) / stride;
@@ -605,7 +608,7 @@ template <int INTEG, bool FULLCTR, int STAGE>
 __global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_kernel(WfArgs a) {
   __shared__ uint32_t alloc_lds[SHADE_BLOCK / 64 + 1];
   __shared__ uint32_t defer_list[SHADE_BLOCK];
-  constexpr bool MIS = (INTEG == EZRT_INTEGRATOR_P5_MIS);
+  constexpr bool MIS = integ_mis<INTEG>();
   constexpr int FORM = store_form<INTEG, STAGE>();
   const uint32_t n_in = (STAGE == 0) ? a.n_slots : *a.n_in;
   const uint32_t stride = gridDim.x * SHADE_BLOCK;
@@ -657,7 +660,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_kernel(WfArgs a) {
 template <int INTEG>
 __global__ __launch_bounds__(BLOCK) void tail_kernel(WfArgs a, int32_t stack_entries) {
   extern __shared__ __attribute__((aligned(16))) int lds_stack[];
-  constexpr bool MIS = (INTEG == EZRT_INTEGRATOR_P5_MIS);
+  constexpr bool MIS = integ_mis<INTEG>();
   constexpr bool COMPACT = compact_state<INTEG>();
   (void)stack_entries;
   const DevScene& sc = a.sc;

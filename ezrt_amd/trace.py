@@ -72,6 +72,10 @@ class Scene:
             cp = _fp(cache)
         self._ck(self._tl.lib.ezrt_scene_set_env(self._h, _fp(hdr), cp, w, h, int(filter)))
 
+    def set_sampler(self, sobol_dims):
+        """8 (default) = the reference's Sobol table, dims wrap d & 7; 16 = eight more dimensions (include/ezrt.h)."""
+        self._ck(self._tl.lib.ezrt_scene_set_sampler(self._h, int(sobol_dims)))
+
     def render(self, params, accum=None):
         """accum: float32 [H, W, 4] running mean (modified in place and returned)."""
         if accum is None:
@@ -161,7 +165,9 @@ class TraceLib:
 
     def debug_math(self, op, a, b=None, n=None):
         """ops 0-9: elementwise det-math; ops 10-12 (intersector audit): a = [n,6] rays,
-        b = [n,6] boxes (10 hitAABB, 12 its v_min3/v_max3 form) or [n,9] triangles (11 hitTriangle)."""
+        b = [n,6] boxes (10 hitAABB, 12 its v_min3/v_max3 form) or [n,9] triangles (11 hitTriangle);
+        ops 13-16 (integrator 52's sampler, frame N = +z): b = [n,6] (roughness, anisotropic, metallic, clearcoat,
+        clearcoatGloss, -), 13: a = [n,6] (V, L) -> pdf, 14/15/16: a = [n,6] (xi1, xi2, xi3, V) -> L.x / L.y / L.z."""
         a = np.ascontiguousarray(a, np.float32)
         bb = np.ascontiguousarray(b, np.float32) if b is not None else np.zeros_like(a)
         n = a.size if n is None else int(n)

@@ -47,6 +47,10 @@ extern "C" {
 #define EZRT_INTEGRATOR_P4_DISNEY 4   /* P4/fsh:478-517  rand() hemisphere, anisotropic Disney   */
 #define EZRT_INTEGRATOR_P5_SOBOL 50   /* P5/fsh:762-807  Sobol+CP hemisphere, isotropic Disney   */
 #define EZRT_INTEGRATOR_P5_MIS 51     /* P5/fsh:810-890  BRDF + env importance sampling, MIS     */
+/* Beyond the reference: chapter 5's loop with the anisotropic specular lobe the reference only
+ * evaluates in chapter 4 (P4/fsh:440-449; commented out in P5/fsh:472-483) evaluated, importance-sampled and
+ * priced: SampleBRDF / BRDF_Pdf with GTR2_aniso (oracle/ezrt_oracle.c sample_gtr2_aniso is the specification). */
+#define EZRT_INTEGRATOR_P5_MIS_ANISO 52
 
 #define EZRT_FILTER_NEAREST 0 /* P3/P4 textures */
 #define EZRT_FILTER_BILINEAR 1 /* P5/main.cpp:196-197 GL_LINEAR */
@@ -92,6 +96,13 @@ void ezrt_scene_destroy(EzrtScene* s);
  * cache may be NULL (integrators 3/4/50 never read it). */
 int ezrt_scene_set_env(EzrtScene* s, const float* hdr, const float* cache, int w, int h, int filter);
 
+/* Sobol dimensions of the integrators 50/51/52 (bounce b draws dimensions 2b, 2b+1).  8 (default) = the
+ * reference's table, P5/fsh:351-353: four bounces, further bounces wrap (d & 7 -- defined here, the shader reads out
+ * of bounds).  16 = eight more dimensions from the tutorial's generator (T5 tutorial.md:267-357) on published
+ * Joe-Kuo parameters (include/ezrt_sobol_v16.inc), wrap d & 15: a different estimator from the ninth dimension on,
+ * the same one for max_bounce <= 4. */
+int ezrt_scene_set_sampler(EzrtScene* s, int sobol_dims);
+
 /* One call = spp iterations of display()'s pass1+pass2 (P5/main.cpp:743-744).
  * accum: host RGBA32F [height][width][4], row 0 = bottom; in = running mean
  * after frame0 samples (ignored when frame0 == 0), out = after frame0+spp. */
@@ -120,7 +131,7 @@ int ezrt_query_hits(EzrtScene* s, const float* rays_od6, int n_rays, int32_t* tr
 int ezrt_tonemap(const float* rgba, int n_pixels, uint8_t* rgb8);
 
 /* Sobol generator of the trace (P5/fsh:351-376): out[i*n_dims+d] =
- * sobol(d, grayCode(index0+i)), d < n_dims <= 8. */
+ * sobol(d, grayCode(index0+i)), d < n_dims <= 16 (dimensions 8-15: see ezrt_scene_set_sampler). */
 int ezrt_sobol(uint32_t index0, int n, int n_dims, float* out);
 
 /* Schedule knobs of the implementation ("packet", "leaf_threshold", "megakernel", ... -- listed in
@@ -146,7 +157,10 @@ int ezrt_scene_stats(EzrtScene* s, int64_t out[6]);
 /* Evaluate the deterministic math definitions on the implementation's compute
  * device (GPU for libezrt_hip) for the bit-equality test.  op: 0 sin, 1 cos,
  * 2 atan2(a,b), 3 asin, 4 log, 5 exp, 6 pow(a,b), 7 sqrt, 8 a/b, 9 wang-hash
- * float of uint bits(a). */
+ * float of uint bits(a).  Ops 10-12 audit the intersector (a = n rays of 6 floats, b = n boxes of 6 / triangles of
+ * 9 floats); ops 13-16 audit integrator 52's sampler in the frame N = (0,0,1) (b = n x (roughness, anisotropic,
+ * metallic, clearcoat, clearcoatGloss, -)): 13: a = n x (V, L) -> its pdf; 14/15/16: a = n x (xi1, xi2, xi3, V)
+ * -> x / y / z of the sampled direction. */
 int ezrt_debug_math(int op, const float* a, const float* b, int n, float* out);
 
 const char* ezrt_last_error(void);

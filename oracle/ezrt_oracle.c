@@ -90,6 +90,7 @@ struct EzrtScene {
   float* cache; /* w*h*3 or NULL */
   int env_w, env_h, env_filter;
   int instr;
+  uint32_t sobol_mask; /* 7: dims wrap d & 7 (default), 15: sixteen dims (ezrt_scene_set_sampler) */
   uint64_t ctr[EZRT_CTR_COUNT];
   int64_t stats[6];
   float last_ms;
@@ -286,9 +287,12 @@ static inline uint32_t wang_hash(uint32_t* seed) {
 }
 static inline float rnd(uint32_t* seed) { return (float)wang_hash(seed) / 4294967296.0f; }
 
-/* Sobol: P5/fsh:351-376; table = the shader literal (8 dims x 32 bits).     */
-static const uint32_t SOBOL_V[8 * 32] = {
+/* Sobol: P5/fsh:351-376; dims 0-7 = the shader literal (8 dims x 32 bits); dims 8-15 (used only
+ * after ezrt_scene_set_sampler(s, 16)) = the tutorial's recurrence (T5 tutorial.md:267-357) on the Joe-Kuo
+ * parameters of dimensions 9-16, tools/gen_sobol_table.py --ext. */
+static const uint32_t SOBOL_V[16 * 32] = {
 #include "ezrt_sobol_v.inc"
+#include "ezrt_sobol_v16.inc"
 };
 static inline uint32_t gray_code(uint32_t i) { return i ^ (i >> 1); }
 static float sobol(uint32_t d, uint32_t i) {
@@ -584,6 +588,72 @@ static float mis_mix_weight(float a, float b) { /* P5/fsh:754-757 */
   return t / (b * b + t);
 }
 
+/* ---- importance sampling of the ANISOTROPIC specular lobe (integrator 52).
+ * The reference stops short of it: chapter 4 evaluates GTR2_aniso but samples the hemisphere uniformly
+ * (P4/fsh:412-473, 478-517); chapter 5 samples the isotropic lobe (SampleGTR2, P5/fsh:593-610) and keeps the
+ * anisotropic evaluate as a commented block (P5/fsh:472-483).  Integrator 52 is chapter 5's loop
+ * (P5/fsh:810-890) with that block switched on and the sampler / pdf that belong to it.  Nothing in the
+ * reference pins these three functions, so the definitions below ARE the specification (evaluation order
+ * as written, shared det-math): the GGX half-vector sampler of Burley 2012 ("Physically Based Shading at
+ * Disney", B.2): h = normalize(sqrt(xi2 / (1 - xi2)) (ax cos(2 pi xi1) X + ay sin(2 pi xi1) Y) + N), whose
+ * density is D(h) (N.h), i.e. pdf(L) = GTR2_aniso(h) N.h / (4 L.h) -- the form BRDF_Pdf uses for the
+ * isotropic lobe (P5/fsh:731). */
+static void aniso_alphas(const Material* m, float* ax, float* ay) { /* P4/fsh:441-443 = P5/fsh:474-476 */
+  float aspect = __builtin_sqrtf(1.0f - m->anisotropic * 0.9f);
+  *ax = ez_max(0.001f, sqr(m->roughness) / aspect);
+  *ay = ez_max(0.001f, sqr(m->roughness) * aspect);
+}
+static v3 sample_gtr2_aniso(float xi1, float xi2, v3 V, v3 N, v3 X, v3 Y, float ax, float ay) {
+  float phi_h = 2.0f * PI * xi1;
+  float sin_phi_h, cos_phi_h;
+  ez_sincos(phi_h, &sin_phi_h, &cos_phi_h);
+  float k = __builtin_sqrtf(xi2 / ez_max(1e-7f, 1.0f - xi2)); /* tan(theta_h) of the unit-roughness lobe */
+  v3 H = vadd(vadd(vscale(X, k * ax * cos_phi_h), vscale(Y, k * ay * sin_phi_h)), N);
+  H = vnormalize(H);
+  return vreflect(vneg(V), H);
+}
+/* SampleBRDF (P5/fsh:633-664) with the specular branch drawing from the anisotropic lobe */
+static v3 sample_brdf_aniso(float xi1, float xi2, float xi3, v3 V, v3 N, v3 X, v3 Y, const Material* m) {
+  float alpha_GTR1 = ez_mix(0.1f, 0.001f, m->clearcoatGloss);
+  float ax, ay;
+  aniso_alphas(m, &ax, &ay);
+  float r_diffuse = 1.0f - m->metallic;
+  float r_specular = 1.0f;
+  float r_clearcoat = 0.25f * m->clearcoat;
+  float r_sum = r_diffuse + r_specular + r_clearcoat;
+  float p_diffuse = r_diffuse / r_sum;
+  float p_specular = r_specular / r_sum;
+  float rd = xi3;
+  if (rd <= p_diffuse) return sample_cosine_hemisphere(xi1, xi2, N);
+  else if (p_diffuse < rd && rd <= p_diffuse + p_specular) return sample_gtr2_aniso(xi1, xi2, V, N, X, Y, ax, ay);
+  else if (p_diffuse + p_specular < rd) return sample_gtr1(xi1, xi2, V, N, alpha_GTR1);
+  return V3(0, 1, 0);
+}
+/* BRDF_Pdf (P5/fsh:715-752) with Ds = GTR2_aniso */
+static float brdf_pdf_aniso(v3 V, v3 N, v3 L, v3 X, v3 Y, const Material* m) {
+  float NdotL = vdot(N, L), NdotV = vdot(N, V);
+  if (NdotL < 0.0f || NdotV < 0.0f) return 0.0f;
+  v3 H = vnormalize(vadd(L, V));
+  float NdotH = vdot(N, H);
+  float LdotH = vdot(L, H);
+  float ax, ay;
+  aniso_alphas(m, &ax, &ay);
+  float Ds = gtr2_aniso(NdotH, vdot(H, X), vdot(H, Y), ax, ay);
+  float Dr = gtr1(NdotH, ez_mix(0.1f, 0.001f, m->clearcoatGloss));
+  float pdf_diffuse = NdotL / PI;
+  float pdf_specular = Ds * NdotH / (4.0f * LdotH);
+  float pdf_clearcoat = Dr * NdotH / (4.0f * LdotH);
+  float r_diffuse = 1.0f - m->metallic;
+  float r_specular = 1.0f;
+  float r_clearcoat = 0.25f * m->clearcoat;
+  float r_sum = r_diffuse + r_specular + r_clearcoat;
+  float p_diffuse = r_diffuse / r_sum;
+  float p_specular = r_specular / r_sum;
+  float p_clearcoat = r_clearcoat / r_sum;
+  float pdf = p_diffuse * pdf_diffuse + p_specular * pdf_specular + p_clearcoat * pdf_clearcoat;
+  return ez_max(1e-10f, pdf);
+}
+
 /* ------------------------------------------------------------------------- */
 /* path logging for ezrt_render_paths                                         */
 typedef struct { int32_t* tri; float* t; int n_slots; } PathLog;
@@ -598,13 +668,15 @@ typedef struct {
   uint32_t frame;
   uint32_t ix, iy;
   uint32_t seed;
+  uint32_t sobol_mask;
 } Sample;
 
 /* sobolVec2 + CP: P5/fsh:372-376, 845-846.  Dimensions beyond the 8 the table
- * holds wrap (d & 7) -- defined here; the reference indexes out of bounds. */
+ * holds wrap (d & 7) -- defined here; the reference indexes out of bounds.  With
+ * ezrt_scene_set_sampler(s, 16) they wrap at 16 instead (8 bounces on distinct dimensions). */
 static void sobol_cp(const Sample* sm, int bounce, float* u, float* v) {
   uint32_t g = gray_code(sm->frame + 1u);
-  uint32_t d0 = ((uint32_t)bounce * 2u) & 7u, d1 = ((uint32_t)bounce * 2u + 1u) & 7u;
+  uint32_t d0 = ((uint32_t)bounce * 2u) & sm->sobol_mask, d1 = ((uint32_t)bounce * 2u + 1u) & sm->sobol_mask;
   *u = sobol(d0, g);
   *v = sobol(d1, g);
   cp_rotation(u, v, sm->ix, sm->iy);
@@ -651,12 +723,17 @@ static v3 path_tracing_uniform(const Ctx* cx, Sample* sm, HitResult hit, PathLog
   return Lo;
 }
 
-/* pathTracingImportanceSampling: P5/fsh:810-890 (integrator 51). */
+/* pathTracingImportanceSampling: P5/fsh:810-890 (integrator 51); integrator 52 = the same loop with the
+ * anisotropic specular lobe evaluated (the block P5/fsh:472-483 keeps commented out = P4/fsh:440-449),
+ * sampled and priced (sample_brdf_aniso / brdf_pdf_aniso above). */
 static v3 path_tracing_mis(const Ctx* cx, Sample* sm, HitResult hit, PathLog* pl) {
   const EzrtRenderParams* p = sm->p;
+  const int aniso = p->integrator == EZRT_INTEGRATOR_P5_MIS_ANISO;
   v3 Lo = V3(0, 0, 0), history = V3(1, 1, 1);
   for (int bounce = 0; bounce < p->max_bounce; bounce++) {
     v3 V = vneg(hit.viewDir), N = hit.normal;
+    v3 X = V3(0, 0, 0), Y = V3(0, 0, 0);
+    if (aniso) get_tangent(N, &X, &Y); /* as chapter 4's loop does, P4/fsh:494-495 */
     float h1 = rnd(&sm->seed);
     float h2 = rnd(&sm->seed);
     v3 Lh = sample_hdr(cx, h1, h2);
@@ -666,8 +743,8 @@ static v3 path_tracing_mis(const Ctx* cx, Sample* sm, HitResult hit, PathLog* pl
       if (!hh.isHit) {
         v3 color = hdr_color(cx, Lh, p->env_clamp);
         float pdf_light = hdr_pdf(cx, Lh);
-        v3 f_r = brdf_evaluate(V, N, Lh, V3(0, 0, 0), V3(0, 0, 0), &hit.material, 0);
-        float pdf_brdf = brdf_pdf(V, N, Lh, &hit.material);
+        v3 f_r = brdf_evaluate(V, N, Lh, X, Y, &hit.material, aniso);
+        float pdf_brdf = aniso ? brdf_pdf_aniso(V, N, Lh, X, Y, &hit.material) : brdf_pdf(V, N, Lh, &hit.material);
         float w = mis_mix_weight(pdf_light, pdf_brdf);
         v3 c = vmul(vmul(vscale(history, w), color), f_r);
         Lo = vadd(Lo, vdivs(vscale(c, vdot(N, Lh)), pdf_light));
@@ -676,13 +753,14 @@ static v3 path_tracing_mis(const Ctx* cx, Sample* sm, HitResult hit, PathLog* pl
     float xi1, xi2;
     sobol_cp(sm, bounce, &xi1, &xi2);
     float xi3 = rnd(&sm->seed);
-    v3 L = sample_brdf(xi1, xi2, xi3, V, N, &hit.material);
+    v3 L = aniso ? sample_brdf_aniso(xi1, xi2, xi3, V, N, X, Y, &hit.material)
+                 : sample_brdf(xi1, xi2, xi3, V, N, &hit.material);
     float NdotL = vdot(N, L);
     if (NdotL <= 0.0f) break;
     HitResult nh = hit_bvh(cx, hit.hitPoint, L);
     plog(pl, 2 + 2 * bounce, &nh);
-    v3 f_r = brdf_evaluate(V, N, L, V3(0, 0, 0), V3(0, 0, 0), &hit.material, 0);
-    float pdf_brdf = brdf_pdf(V, N, L, &hit.material);
+    v3 f_r = brdf_evaluate(V, N, L, X, Y, &hit.material, aniso);
+    float pdf_brdf = aniso ? brdf_pdf_aniso(V, N, L, X, Y, &hit.material) : brdf_pdf(V, N, L, &hit.material);
     if (pdf_brdf <= 0.0f) break;
     if (!nh.isHit) {
       v3 color = hdr_color(cx, L, p->env_clamp);
@@ -709,6 +787,7 @@ static v3 trace_sample(const Ctx* cx, const EzrtRenderParams* p, uint32_t ix, ui
   sm.ix = ix;
   sm.iy = iy;
   sm.seed = (ix * 1973u + iy * 9277u + frame * 26699u) | 1u; /* P5/fsh:315-318 */
+  sm.sobol_mask = cx->s->sobol_mask;
   cx->ctr->c[EZRT_CTR_SAMPLES]++;
   float W = (float)p->width, H = (float)p->height;
   float pixx = ((float)ix + 0.5f) / W * 2.0f - 1.0f;
@@ -725,7 +804,8 @@ static v3 trace_sample(const Ctx* cx, const EzrtRenderParams* p, uint32_t ix, ui
   plog(pl, 0, &first);
   if (!first.isHit) return hdr_color(cx, dir, p->env_clamp);
   v3 Le = first.material.emissive;
-  v3 Li = (p->integrator == EZRT_INTEGRATOR_P5_MIS) ? path_tracing_mis(cx, &sm, first, pl)
+  v3 Li = (p->integrator == EZRT_INTEGRATOR_P5_MIS || p->integrator == EZRT_INTEGRATOR_P5_MIS_ANISO)
+              ? path_tracing_mis(cx, &sm, first, pl)
                                                     : path_tracing_uniform(cx, &sm, first, pl);
   return vadd(Le, Li);
 }
@@ -739,7 +819,7 @@ static int validate_params(const EzrtRenderParams* p) {
   if (p->x0 < 0 || p->y0 < 0 || p->x1 > p->width || p->y1 > p->height || p->x0 > p->x1 || p->y0 > p->y1)
     return fail(EZRT_ERR_INVALID, "pixel rect outside the image");
   if (p->max_bounce < 0 || p->max_bounce > 64) return fail(EZRT_ERR_INVALID, "max_bounce out of range [0,64]");
-  if (p->integrator != 3 && p->integrator != 4 && p->integrator != 50 && p->integrator != 51)
+  if (p->integrator != 3 && p->integrator != 4 && p->integrator != 50 && p->integrator != 51 && p->integrator != 52)
     return fail(EZRT_ERR_INVALID, "unknown integrator");
   if (p->shard_count < 0 || p->shard_index < 0 || (p->shard_count > 0 && p->shard_index >= p->shard_count))
     return fail(EZRT_ERR_INVALID, "bad shard index/count");
@@ -807,6 +887,7 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
   if (!s) return fail(EZRT_ERR_NOMEM, "out of memory");
   s->n_tri = n_tri;
   s->n_nodes = n_nodes;
+  s->sobol_mask = 7u;
   s->tri = (float*)malloc((size_t)n_tri * 36 * sizeof(float));
   s->nodes = (float*)malloc((size_t)n_nodes * 12 * sizeof(float));
   if (!s->tri || !s->nodes) {
@@ -873,7 +954,7 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum, vo
   if (!s || !accum) return fail(EZRT_ERR_INVALID, "scene/accum is NULL");
   int rc = validate_params(p);
   if (rc) return rc;
-  if (p->integrator == EZRT_INTEGRATOR_P5_MIS && !s->cache)
+  if ((p->integrator == EZRT_INTEGRATOR_P5_MIS || p->integrator == EZRT_INTEGRATOR_P5_MIS_ANISO) && !s->cache)
     return fail(EZRT_ERR_INVALID, "integrator 51 needs the env cache (ezrt_scene_set_env)");
   double t0 = now_ms();
   Ctr total;
@@ -934,7 +1015,7 @@ int ezrt_render_paths(EzrtScene* s, const EzrtRenderParams* p, int32_t* tri_id, 
   if (!s || !tri_id || !t_hit) return fail(EZRT_ERR_INVALID, "NULL argument");
   int rc = validate_params(p);
   if (rc) return rc;
-  if (p->integrator == EZRT_INTEGRATOR_P5_MIS && !s->cache)
+  if ((p->integrator == EZRT_INTEGRATOR_P5_MIS || p->integrator == EZRT_INTEGRATOR_P5_MIS_ANISO) && !s->cache)
     return fail(EZRT_ERR_INVALID, "integrator 51 needs the env cache (ezrt_scene_set_env)");
   int slots = 1 + 2 * p->max_bounce;
   Ctr total;
@@ -1026,9 +1107,15 @@ int ezrt_tonemap(const float* rgba, int n_pixels, uint8_t* rgb8) {
 }
 
 int ezrt_sobol(uint32_t index0, int n, int n_dims, float* out) {
-  if (!out || n < 0 || n_dims < 1 || n_dims > 8) return fail(EZRT_ERR_INVALID, "bad sobol arguments");
+  if (!out || n < 0 || n_dims < 1 || n_dims > 16) return fail(EZRT_ERR_INVALID, "bad sobol arguments");
   for (int i = 0; i < n; i++)
     for (int d = 0; d < n_dims; d++) out[(size_t)i * n_dims + d] = sobol((uint32_t)d, gray_code(index0 + (uint32_t)i));
+  return 0;
+}
+
+int ezrt_scene_set_sampler(EzrtScene* s, int sobol_dims) {
+  if (!s || (sobol_dims != 8 && sobol_dims != 16)) return fail(EZRT_ERR_INVALID, "sobol_dims must be 8 or 16");
+  s->sobol_mask = (uint32_t)sobol_dims - 1u;
   return 0;
 }
 
@@ -1073,6 +1160,30 @@ int ezrt_debug_math(int op, const float* a, const float* b, int n, float* out) {
     for (int i = 0; i < n; i++) {
       const float *r = a + 6 * (size_t)i, *q = b + 6 * (size_t)i;
       out[i] = hit_aabb(V3(r[0], r[1], r[2]), V3(r[3], r[4], r[5]), V3(q[0], q[1], q[2]), V3(q[3], q[4], q[5]));
+    }
+    return 0;
+  }
+  if (op >= 13 && op <= 16) { /* f4 audit in the frame N = (0,0,1), X/Y = getTangent(N).  b = n x (roughness,
+                               * anisotropic, metallic, clearcoat, clearcoatGloss, -).  13: a = n x (V, L) ->
+                               * brdf_pdf_aniso; 14/15/16: a = n x (xi1, xi2, xi3, V) -> sample_brdf_aniso .x/.y/.z */
+    if (!b) return fail(EZRT_ERR_INVALID, "NULL argument");
+    for (int i = 0; i < n; i++) {
+      const float *r = a + 6 * (size_t)i, *q = b + 6 * (size_t)i;
+      Material m;
+      memset(&m, 0, sizeof m);
+      m.roughness = q[0];
+      m.anisotropic = q[1];
+      m.metallic = q[2];
+      m.clearcoat = q[3];
+      m.clearcoatGloss = q[4];
+      v3 N = V3(0, 0, 1), X, Y;
+      get_tangent(N, &X, &Y);
+      if (op == 13) {
+        out[i] = brdf_pdf_aniso(V3(r[0], r[1], r[2]), N, V3(r[3], r[4], r[5]), X, Y, &m);
+      } else {
+        v3 L = sample_brdf_aniso(r[0], r[1], r[2], V3(r[3], r[4], r[5]), N, X, Y, &m);
+        out[i] = op == 14 ? L.x : (op == 15 ? L.y : L.z);
+      }
     }
     return 0;
   }

@@ -72,3 +72,52 @@ def test_gpu_sobol_kernel_matches_known_answers_and_oracle(hip, oracle):
     got = hip.sobol(0, 30, 3)
     assert np.array_equal(got, np.array(KAT["points"], np.float32))
     assert np.array_equal(hip.sobol(1, 4096, 8), oracle.sobol(1, 4096, 8))
+
+
+# ----------------------------------------------------------------------------- dimensions 8-15
+def _table16():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gen_sobol_table import direction_numbers, direction_numbers_ext
+    return direction_numbers() + direction_numbers_ext()
+
+
+def test_extension_table_is_the_committed_include():
+    inc = open(os.path.join(ROOT, "include", "ezrt_sobol_v16.inc")).read()
+    nums = [int(x) for x in re.findall(r"(\d+)u,", inc)]
+    assert nums == [x for row in _table16()[8:] for x in row] and len(nums) == 8 * 32
+
+
+def test_extension_dims_are_nets_with_unit_triangular_generator_matrices():
+    """Word k of a Joe-Kuo row is m_k << (31 - k) with m_k odd and < 2^(k+1): bit (31 - k) is set and no higher
+    bit (the generator matrix is unit upper triangular), which is what makes every 2^m prefix a (0, m, 1)-net;
+    checked on the bits and on the points."""
+    table = _table16()
+    for d in range(8, 16):
+        for k, w in enumerate(table[d]):
+            assert (w >> (31 - k)) & 1 == 1 and w % (1 << (31 - k)) == 0, (d, k)
+        for m in (4, 6, 9):
+            pts = np.array([_py_sobol(table, d, i) for i in range(1 << m)], np.float64)
+            assert sorted((pts * (1 << m)).astype(int).tolist()) == list(range(1 << m)), (d, m)
+
+
+def test_no_two_of_the_sixteen_rows_share_a_tail():
+    """No pair of rows may agree in more than a few (early, small-m) words -- two dimensions with a common tail
+    would be the same sequence from some sample index on."""
+    table = _table16()
+    for i in range(16):
+        for j in range(i + 1, 16):
+            same = sum(1 for k in range(2, 32) if table[i][k] == table[j][k])
+            assert same <= 3, (i, j, same)
+
+
+def test_oracle_sixteen_dims_match_table_formula(oracle):
+    table = _table16()
+    got = oracle.sobol(0, 300, 16)
+    want = np.array([[_py_sobol(table, d, i) for d in range(16)] for i in range(300)], np.float32)
+    assert np.array_equal(got, want)
+    assert np.array_equal(got[:, :8], oracle.sobol(0, 300, 8))
+
+
+@pytest.mark.gpu
+def test_gpu_sobol_sixteen_dims_match_oracle(hip, oracle):
+    assert np.array_equal(hip.sobol(1, 4096, 16), oracle.sobol(1, 4096, 16))
