@@ -11,7 +11,7 @@ ARCH ?= gfx950
 
 LIBDIR = ezrt_amd/lib
 HOST_SRC = ezrt_amd/csrc/host/scene.cpp ezrt_amd/csrc/host/hdr.cpp ezrt_amd/csrc/host/p2_query.cpp ezrt_amd/csrc/host/host_c_api.cpp
-HIP_SRC = ezrt_amd/csrc/hip/ezrt_hip.hip ezrt_amd/csrc/hip/ezrt_lbvh.hip ezrt_amd/csrc/hip/ezrt_sahbvh.hip
+HIP_SRC = ezrt_amd/csrc/hip/ezrt_hip.hip ezrt_amd/csrc/hip/ezrt_lbvh.hip ezrt_amd/csrc/hip/ezrt_sahbvh.hip ezrt_amd/csrc/hip/ezrt_mgpu.hip
 HIP_DEPS = $(wildcard ezrt_amd/csrc/hip/*.h) $(wildcard ezrt_amd/csrc/hip/*.hip) $(wildcard include/*)
 
 # -ffp-contract=off everywhere: the trace's discrete decisions must be
@@ -34,7 +34,7 @@ $(LIBDIR)/libezrt_scene.so: $(HOST_SRC) include/ezrt_scene.hpp include/ezrt_scen
 
 $(LIBDIR)/libezrt_hip.so: $(HIP_DEPS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIP_FLAGS) -shared -o $@ $(HIP_SRC)
+	$(HIPCC) $(HIP_FLAGS) -shared -o $@ $(HIP_SRC) -ldl
 
 # Consumers of the public headers outside the libraries: chapter 5's main() ported onto the C ABI + the
 # C++ host API (g++ only: the boundary needs no HIP header), and a C11 layout check of the by-value struct.

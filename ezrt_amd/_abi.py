@@ -103,6 +103,28 @@ BUILD_ABI = {
 }
 
 
+# include/ezrt_mgpu.h: one process, N devices (both libraries: the oracle's "devices" are host memory)
+MGPU_ABI = {
+    "ezrt_mgpu_create": (C.c_int, [c_float_p, C.c_int, c_float_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int,
+                                   C.POINTER(C.c_void_p)]),
+    "ezrt_mgpu_destroy": (None, [C.c_void_p]),
+    "ezrt_mgpu_set_env": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_int, C.c_int, C.c_int]),
+    "ezrt_mgpu_set_sampler": (C.c_int, [C.c_void_p, C.c_int]),
+    "ezrt_mgpu_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "ezrt_mgpu_render": (C.c_int, [C.c_void_p, C.POINTER(EzrtRenderParams)]),
+    "ezrt_mgpu_gather": (C.c_int, [C.c_void_p, c_float_p]),
+    "ezrt_mgpu_frame_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ezrt_mgpu_counters": (C.c_int, [C.c_void_p, c_uint64_p]),
+    "ezrt_mgpu_last_ms": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_int64_p]),
+    "ezrt_tiles_packed_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ezrt_tiles_pack_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_void_p]),
+    "ezrt_tiles_unpack_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_void_p]),
+}
+TRANSPORT_RCCL, TRANSPORT_PEER, TRANSPORT_HOST = 0, 1, 2
+
+
 def _declare(lib, table):
     for name, (res, args) in table.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
@@ -112,7 +134,7 @@ def _declare(lib, table):
 
 
 def declare_trace_abi(lib):
-    return _declare(lib, TRACE_ABI)
+    return _declare(_declare(lib, TRACE_ABI), MGPU_ABI)
 
 
 def declare_host_abi(lib):

@@ -74,10 +74,41 @@ class TilePlan:
         return self.from_tiles(tiles)
 
 
-def gather_frame(accum, plan, rank, dist, dst=0, via_cpu=False):
+def _gather_frame_native(accum, plan, rank, dist, dst, lib, via_cpu=False):
+    """gather_frame with the library's own kernels around the collective (include/ezrt_mgpu.h: ezrt_tiles_pack_device
+    on every rank, ezrt_tiles_unpack_device per peer on `dst`): the layout and kernels of the one-process
+    ezrt_mgpu_gather, with torch.distributed (RCCL) as the transport.  Assembles IN PLACE: on `dst` the rank's own frame
+    buffer already holds its tiles and receives the peers'.  CPU tensors work with the oracle build of the header."""
+    assert accum.is_contiguous() and accum.dtype == torch.float32 and accum.shape == (plan.height, plan.width, 4)
+    st = torch.cuda.current_stream(accum.device).cuda_stream if accum.is_cuda else None
+    args = (plan.width, plan.height, plan.tile_w, plan.tile_h)
+    n = plan.per_rank * plan.tile_h * plan.tile_w * 4   # equal-size payloads for the collective (<= one tile of padding)
+    packed = torch.zeros(n, dtype=torch.float32, device=accum.device)
+    if lib.ezrt_tiles_pack_device(accum.data_ptr(), *args, rank, plan.world, packed.data_ptr(), st) != 0:
+        raise RuntimeError(lib.ezrt_last_error().decode())
+    if via_cpu:
+        packed = packed.cpu()
+    if rank != dst:
+        dist.gather(packed, gather_list=None, dst=dst)
+        return accum
+    bufs = [torch.empty_like(packed) for _ in range(plan.world)]
+    dist.gather(packed, gather_list=bufs, dst=dst)
+    if via_cpu:
+        bufs = [b.to(accum.device) for b in bufs]
+    for r in range(plan.world):
+        if r != dst and lib.ezrt_tiles_unpack_device(bufs[r].data_ptr(), *args, r, plan.world, accum.data_ptr(), st) != 0:
+            raise RuntimeError(lib.ezrt_last_error().decode())
+    return accum
+
+
+def gather_frame(accum, plan, rank, dist, dst=0, via_cpu=False, lib=None):
     """Close a frame: one gather of every rank's packed tiles to `dst`.  Returns the assembled
     [H, W, C] frame on `dst` and the rank's own buffer elsewhere.  via_cpu stages the payload
-    through host memory (gloo debugging of the GPU driver script; never used with RCCL)."""
+    through host memory (gloo debugging of the GPU driver script; never used with RCCL).
+    lib (a CDLL exporting include/ezrt_mgpu.h): pack / un-permute with the library's kernels instead of torch
+    indexing, in place."""
+    if lib is not None:
+        return _gather_frame_native(accum, plan, rank, dist, dst, lib, via_cpu)
     packed = plan.pack(accum, rank)
     if via_cpu:
         packed = packed.cpu()

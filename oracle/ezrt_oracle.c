@@ -1224,3 +1224,169 @@ int ezrt_debug_math(int op, const float* a, const float* b, int n, float* out) {
   }
   return 0;
 }
+
+/* ------------------------------------------------------------------------- */
+/* include/ezrt_mgpu.h on the CPU: N shards of one frame rendered by the functions above, "transport" = memcpy.
+ * Checks the sharding + pack / un-permute index rules (include/ezrt_tiles.h) without a GPU; device ordinals are
+ * accepted and ignored. */
+#include "ezrt_mgpu.h"
+#include "ezrt_tiles.h"
+
+struct EzrtMgpu {
+  int n;
+  EzrtScene* sc;       /* one scene serves every shard: host memory is shared */
+  float** accum;       /* [n] full-size frame buffers, shard i valid in accum[i] */
+  int width, height;
+  EzrtRenderParams last;
+  int have_last;
+  float gather_ms;
+  int64_t gather_bytes;
+  float* render_ms;
+};
+
+int ezrt_mgpu_create(const float* tri, int n_tri, const float* nodes, int n_nodes, const int* devices, int n_devices,
+                     int transport, EzrtMgpu** out) {
+  if (!out) return fail(EZRT_ERR_INVALID, "out is NULL");
+  *out = NULL;
+  if (!devices || n_devices < 1 || n_devices > 64) return fail(EZRT_ERR_INVALID, "need 1..64 devices");
+  if (transport < 0 || transport > 2) return fail(EZRT_ERR_INVALID, "unknown transport");
+  EzrtMgpu* m = (EzrtMgpu*)calloc(1, sizeof *m);
+  if (!m) return fail(EZRT_ERR_NOMEM, "out of memory");
+  m->n = n_devices;
+  int rc = ezrt_scene_create(tri, n_tri, nodes, n_nodes, &m->sc);
+  if (rc) {
+    free(m);
+    return rc;
+  }
+  m->accum = (float**)calloc((size_t)n_devices, sizeof(float*));
+  m->render_ms = (float*)calloc((size_t)n_devices, sizeof(float));
+  *out = m;
+  return 0;
+}
+void ezrt_mgpu_destroy(EzrtMgpu* m) {
+  if (!m) return;
+  for (int i = 0; i < m->n; i++) free(m->accum[i]);
+  free(m->accum);
+  free(m->render_ms);
+  ezrt_scene_destroy(m->sc);
+  free(m);
+}
+int ezrt_mgpu_set_env(EzrtMgpu* m, const float* hdr, const float* cache, int w, int h, int filter) {
+  if (!m) return fail(EZRT_ERR_INVALID, "NULL argument");
+  return ezrt_scene_set_env(m->sc, hdr, cache, w, h, filter);
+}
+int ezrt_mgpu_set_sampler(EzrtMgpu* m, int sobol_dims) {
+  if (!m) return fail(EZRT_ERR_INVALID, "NULL argument");
+  return ezrt_scene_set_sampler(m->sc, sobol_dims);
+}
+int ezrt_mgpu_set_option(EzrtMgpu* m, const char* name, int value) {
+  if (!m) return fail(EZRT_ERR_INVALID, "NULL argument");
+  return ezrt_set_option(m->sc, name, value);
+}
+int ezrt_mgpu_render(EzrtMgpu* m, const EzrtRenderParams* p) {
+  if (!m || !p) return fail(EZRT_ERR_INVALID, "NULL argument");
+  if (p->width <= 0 || p->height <= 0) return fail(EZRT_ERR_INVALID, "width/height must be positive");
+  if (p->width != m->width || p->height != m->height) {
+    for (int i = 0; i < m->n; i++) {
+      free(m->accum[i]);
+      m->accum[i] = (float*)calloc((size_t)p->width * p->height * 4, sizeof(float));
+      if (!m->accum[i]) return fail(EZRT_ERR_NOMEM, "out of memory");
+    }
+    m->width = p->width;
+    m->height = p->height;
+  }
+  for (int i = 0; i < m->n; i++) {
+    EzrtRenderParams s = *p;
+    s.shard_index = i;
+    s.shard_count = m->n;
+    int rc = ezrt_render_device(m->sc, &s, m->accum[i], NULL);
+    if (rc) return rc;
+    m->render_ms[i] = m->sc->last_ms;
+  }
+  m->last = *p;
+  m->have_last = 1;
+  return 0;
+}
+int ezrt_mgpu_gather(EzrtMgpu* m, float* accum_rgba) {
+  if (!m) return fail(EZRT_ERR_INVALID, "NULL argument");
+  if (!m->have_last) return fail(EZRT_ERR_INVALID, "ezrt_mgpu_gather before any ezrt_mgpu_render");
+  double t0 = now_ms();
+  const EzrtTilePlan plan = ezrt_tile_plan(m->width, m->height, m->last.tile_w, m->last.tile_h, m->n);
+  size_t total = 0;
+  for (int i = 1; i < m->n; i++) {
+    const size_t cnt = ezrt_tiles_packed_texels(&plan, i);
+    float* packed = (float*)malloc((cnt ? cnt : 1) * 4 * sizeof(float));
+    float* recv = (float*)malloc((cnt ? cnt : 1) * 4 * sizeof(float));
+    if (!packed || !recv) {
+      free(packed);
+      free(recv);
+      return fail(EZRT_ERR_NOMEM, "out of memory");
+    }
+    for (size_t k = 0; k < cnt; k++) { /* pack on "device" i */
+      int x, y;
+      if (ezrt_tiles_packed_to_pixel(&plan, i, k, &x, &y)) memcpy(packed + 4 * k, m->accum[i] + ((size_t)y * m->width + x) * 4, 16);
+      else memset(packed + 4 * k, 0, 16);
+    }
+    memcpy(recv, packed, cnt * 16); /* the "transport" */
+    for (size_t k = 0; k < cnt; k++) { /* un-permute on the root */
+      int x, y;
+      if (ezrt_tiles_packed_to_pixel(&plan, i, k, &x, &y)) memcpy(m->accum[0] + ((size_t)y * m->width + x) * 4, recv + 4 * k, 16);
+    }
+    free(packed);
+    free(recv);
+    total += cnt;
+  }
+  m->gather_ms = (float)(now_ms() - t0);
+  m->gather_bytes = (int64_t)(total * 16);
+  if (accum_rgba) memcpy(accum_rgba, m->accum[0], (size_t)m->width * m->height * 16);
+  return 0;
+}
+int ezrt_mgpu_frame_device(EzrtMgpu* m, float** frame_dev) {
+  if (!m || !frame_dev) return fail(EZRT_ERR_INVALID, "NULL argument");
+  if (!m->accum[0]) return fail(EZRT_ERR_INVALID, "no frame yet");
+  *frame_dev = m->accum[0];
+  return 0;
+}
+int ezrt_mgpu_counters(EzrtMgpu* m, uint64_t out[EZRT_CTR_COUNT]) {
+  if (!m || !out) return fail(EZRT_ERR_INVALID, "NULL argument");
+  return ezrt_counters(m->sc, out);
+}
+int ezrt_mgpu_last_ms(EzrtMgpu* m, float* render_ms, float* gather_ms, int64_t* gather_bytes) {
+  if (!m) return fail(EZRT_ERR_INVALID, "NULL argument");
+  if (render_ms) memcpy(render_ms, m->render_ms, (size_t)m->n * sizeof(float));
+  if (gather_ms) *gather_ms = m->gather_ms;
+  if (gather_bytes) *gather_bytes = m->gather_bytes;
+  return 0;
+}
+int64_t ezrt_tiles_packed_floats(int width, int height, int tile_w, int tile_h, int rank, int world) {
+  if (width <= 0 || height <= 0 || world <= 0 || rank < 0 || rank >= world) return -1;
+  const EzrtTilePlan plan = ezrt_tile_plan(width, height, tile_w, tile_h, world);
+  return (int64_t)(ezrt_tiles_packed_texels(&plan, rank) * 4);
+}
+int ezrt_tiles_pack_device(const float* accum_dev, int width, int height, int tile_w, int tile_h, int rank, int world,
+                           float* packed_dev, void* stream) {
+  (void)stream;
+  if (!accum_dev || !packed_dev || width <= 0 || height <= 0 || world <= 0 || rank < 0 || rank >= world)
+    return fail(EZRT_ERR_INVALID, "bad argument");
+  const EzrtTilePlan plan = ezrt_tile_plan(width, height, tile_w, tile_h, world);
+  const size_t cnt = ezrt_tiles_packed_texels(&plan, rank);
+  for (size_t k = 0; k < cnt; k++) {
+    int x, y;
+    if (ezrt_tiles_packed_to_pixel(&plan, rank, k, &x, &y)) memcpy(packed_dev + 4 * k, accum_dev + ((size_t)y * width + x) * 4, 16);
+    else memset(packed_dev + 4 * k, 0, 16);
+  }
+  return 0;
+}
+int ezrt_tiles_unpack_device(const float* packed_dev, int width, int height, int tile_w, int tile_h, int rank, int world,
+                             float* accum_dev, void* stream) {
+  (void)stream;
+  if (!accum_dev || !packed_dev || width <= 0 || height <= 0 || world <= 0 || rank < 0 || rank >= world)
+    return fail(EZRT_ERR_INVALID, "bad argument");
+  const EzrtTilePlan plan = ezrt_tile_plan(width, height, tile_w, tile_h, world);
+  const size_t cnt = ezrt_tiles_packed_texels(&plan, rank);
+  for (size_t k = 0; k < cnt; k++) {
+    int x, y;
+    if (ezrt_tiles_packed_to_pixel(&plan, rank, k, &x, &y)) memcpy(accum_dev + ((size_t)y * width + x) * 4, packed_dev + 4 * k, 16);
+  }
+  return 0;
+}

@@ -41,6 +41,15 @@ def test_binding_table_matches_header():
     assert set(_declared("ezrt.h")) == set(_abi.TRACE_ABI)
 
 
+def test_mgpu_binding_table_matches_header_in_both_libraries(oracle):
+    from ezrt_amd import _abi
+    names = _declared("ezrt_mgpu.h")
+    assert set(names) == set(_abi.MGPU_ABI) and len(names) == 13
+    hip = _abi.load_hip()  # dlopen only
+    for n in names:
+        assert hasattr(hip, n) and hasattr(oracle.lib, n), n
+
+
 def test_params_struct_layout_matches_header():
     from ezrt_amd import _abi
     # 6 ints + 2 uints + 2 ints + 3 + 16 floats + 1 float + 4 ints = 34 x 4 bytes

@@ -68,9 +68,12 @@ def _worker(rank, world, port, out_path):
     accum = np.zeros((H, W, 4), np.float32)
     sc.render(p, accum)
     frame = tiles.gather_frame(torch.from_numpy(accum), plan, rank, dist)
+    # the same close through the C entry points of include/ezrt_mgpu.h (ezrt_tiles_pack_device / _unpack_device; here the
+    # oracle's build of them, host memory as the transport's end points), in place in the rank's frame buffer
+    native = tiles.gather_frame(torch.from_numpy(accum.copy()), plan, rank, dist, lib=ora.lib)
     if rank == 0:
         full = sc.render(trace.make_params(W, H, eye, cam, 50, 3, spp=3))
-        np.save(out_path, np.stack([frame.numpy(), full]))
+        np.save(out_path, np.stack([frame.numpy(), full, native.numpy()]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -80,5 +83,6 @@ def test_two_rank_gloo_gather_equals_single_process_frame(tmp_path, oracle):
     out = str(tmp_path / "frames.npy")
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
-    got, want = np.load(out)
+    got, want, native = np.load(out)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(native.view(np.uint32), want.view(np.uint32))
