@@ -868,8 +868,11 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
   }
   if (maxd + 1 > 256) return fail(EZRT_ERR_UNSUPPORTED, "tree deeper than the reference's 256-entry stack");
   if (maxleaf > 128) return fail(EZRT_ERR_UNSUPPORTED, "leaf with %lld triangles: this build packs leaf size in 7 bits (<= 128)", (long long)maxleaf);
-  if ((size_t)maxd * BLOCK * sizeof(int) > 150 * 1024)
-    return fail(EZRT_ERR_UNSUPPORTED, "tree depth %d needs more LDS stack than one CU has", maxd);
+  // per-lane traversal stack in LDS: depth rows of 256 ints + the lane table must fit the 64 KiB a workgroup gets
+  // without an opt-in (every kernel that walks the tree is launched with that much dynamic LDS at most)
+  if (((size_t)maxd + 1) * BLOCK * sizeof(int) > 64 * 1024)
+    return fail(EZRT_ERR_UNSUPPORTED, "tree depth %d: the LDS traversal stack of this build holds depth <= 63 (the reference's is 256 entries; "
+                "its builders reach depth ~30 on 10^6 triangles)", maxd);
 
   // ---- device layout.  Inner records are numbered breadth-first from the root (ids are internal
   // to the device layout) so that records [0, K) are the top levels of the tree: traceq_kernel stages

@@ -31,9 +31,10 @@ struct Reader {
 typedef unsigned char RGBE[4];
 
 // oldDecrunch: hdrloader.cpp:182-212 (flat RGBE with optional old-style runs)
-bool old_decrunch(RGBE* scan, int len, Reader& f) {
+// `base` = first pixel of the scanline: a run copies the previous pixel, which exists from the second pixel of the
+// LINE on (decrunch's fallback enters at scan + 1 with pixel 0 already written, hdrloader.cpp:135-139).
+bool old_decrunch(RGBE* scan, int len, Reader& f, RGBE* base) {
   int rshift = 0;
-  RGBE* base = scan;
   while (len > 0) {
     int r = f.get(), g = f.get(), b = f.get(), x = f.get();
     if (f.eof) return false;
@@ -42,7 +43,9 @@ bool old_decrunch(RGBE* scan, int len, Reader& f) {
     scan[0][2] = (unsigned char)b;
     scan[0][3] = (unsigned char)x;
     if (r == 1 && g == 1 && b == 1) {
-      if (scan == base) return false; // a run needs a previous pixel
+      if (scan == base) return false; // a run needs a previous pixel (the reference reads before the buffer)
+      if (rshift >= 24) return false; // four run markers in a row: `x << rshift` leaves int (undefined in the reference);
+                                      // no scanline (len <= 0x7fff on this path, any len in practice) is that long
       for (int i = x << rshift; i > 0 && len > 0; i--) {
         memcpy(&scan[0][0], &scan[-1][0], 4);
         scan++;
@@ -60,11 +63,11 @@ bool old_decrunch(RGBE* scan, int len, Reader& f) {
 
 // decrunch: hdrloader.cpp:139-180 (new-style per-component RLE)
 bool decrunch(RGBE* scan, int len, Reader& f) {
-  if (len < 8 || len > 0x7fff) return old_decrunch(scan, len, f);
+  if (len < 8 || len > 0x7fff) return old_decrunch(scan, len, f, scan);
   int i = f.get();
   if (i != 2) {
     f.unget();
-    return old_decrunch(scan, len, f);
+    return old_decrunch(scan, len, f, scan);
   }
   scan[0][1] = (unsigned char)f.get();
   scan[0][2] = (unsigned char)f.get();
@@ -72,7 +75,7 @@ bool decrunch(RGBE* scan, int len, Reader& f) {
   if (scan[0][1] != 2 || (scan[0][2] & 128)) {
     scan[0][0] = 2;
     scan[0][3] = (unsigned char)i;
-    return old_decrunch(scan + 1, len - 1, f);
+    return old_decrunch(scan + 1, len - 1, f, scan);
   }
   for (int comp = 0; comp < 4; comp++) {
     for (int j = 0; j < len;) {

@@ -9,7 +9,7 @@ handlers of the reference do for a user (P3/main.cpp:596-672), minus the window.
 A camera change only resets the counter: frame 0 ignores the previous frame-buffer content (the
 reference multiplies it by 0), so the buffer is not cleared.  A checkpoint is {frame buffer, frame
 counter, camera, render settings}; resuming from it continues the running mean exactly where it
-stopped -- the result is bit-identical to an uninterrupted run (tests/test_gpu_progressive.py)."""
+stopped -- the result is bit-identical to an uninterrupted run (tests/test_progressive.py)."""
 import json
 
 import numpy as np

@@ -110,7 +110,11 @@ int ezrt_render(EzrtScene* s, const EzrtRenderParams* p, float* accum_rgba);
 
 /* Same, but accum is a device pointer (HBM-resident lastFrame) and the work is
  * enqueued on `stream` (a hipStream_t, NULL = default stream) without a host
- * sync.  In the oracle library "device" memory is host memory. */
+ * sync.  In the oracle library "device" memory is host memory.
+ * ONE STREAM PER SCENE: the queues, counters and block list of a render call are
+ * scratch owned by the EzrtScene, so calls on one scene must be ordered -- same
+ * stream, or the caller synchronises between streams.  Scenes are independent:
+ * concurrent streams (or devices, include/ezrt_mgpu.h) take one scene each. */
 int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_rgba_dev, void* stream);
 
 /* Parity audit: render exactly one frame (p->frame0, spp ignored) and report

@@ -330,3 +330,53 @@ def test_deep_skewed_tree_uses_many_stack_rows(hip, oracle):
     tg, dg = sg.query_hits(rays)
     to, do = so.query_hits(rays)
     assert np.array_equal(tg, to) and np.array_equal(_bits(dg), _bits(do))
+
+
+def _chain_tree(n_inner):
+    """A degenerate tree: inner node k has leaf k (one triangle) on the left and inner node k + 1 on the right; the last
+    inner node has two leaves.  Depth = n_inner + 1.  Returns (tri[n,36], nodes[m,12]) in the reference encoding."""
+    n = n_inner + 1
+    rng = np.random.default_rng(9)
+    T = np.zeros((n, 36), np.float32)
+    c = np.stack([np.linspace(-3, 3, n), rng.uniform(-0.3, 0.3, n), rng.uniform(-0.3, 0.3, n)], 1)
+    P = (c[:, None, :] + rng.uniform(-0.15, 0.15, (n, 3, 3))).astype(np.float32)
+    T[:, :9] = P.reshape(n, 9)
+    T[:, 9:18] = np.tile([0, 0, 1], 3)
+    T[:, 18:36] = S.Material.disney(baseColor=(0.8, 0.6, 0.4)).to18()
+    lo = np.minimum.accumulate(P.min(axis=1)[::-1], axis=0)[::-1]   # box of triangles k..n-1
+    hi = np.maximum.accumulate(P.max(axis=1)[::-1], axis=0)[::-1]
+    nodes = np.zeros((1 + 2 * n_inner + 1, 12), np.float32)
+    inner_id = lambda k: 1 + 2 * k          # inner k, followed by its left leaf
+    for k in range(n_inner):
+        i = inner_id(k)
+        last = k == n_inner - 1
+        nodes[i] = [i + 1, i + 2, 0, 0, 0, 0, *lo[k], *hi[k]]
+        nodes[i + 1] = [0, 0, 0, 1, k, 0, *P[k].min(axis=0), *P[k].max(axis=0)]
+        if last:
+            nodes[i + 2] = [0, 0, 0, 1, k + 1, 0, *P[k + 1].min(axis=0), *P[k + 1].max(axis=0)]
+    return T, nodes
+
+
+@pytest.mark.gpu
+def test_deepest_supported_tree_renders_and_deeper_ones_are_refused_at_create(hip, oracle):
+    """The LDS traversal stack holds depth <= 63 (deeper trees used to pass ezrt_scene_create and then fail
+    every launch with a generic error)."""
+    tri, nodes = _chain_tree(62)              # depth 63
+    sg, so = hip.scene_create(tri, nodes), oracle.scene_create(tri, nodes)
+    assert sg.stats()["depth"] == 63
+    hdr = scenes.synthetic_hdr(64, 32)
+    sg.set_env(hdr, None, 1)
+    so.set_env(hdr, None, 1)
+    eye, cam = S.camera(30, 5, 6)
+    p = trace.make_params(96, 64, eye, cam, 50, 2, spp=2)
+    assert np.array_equal(_bits(sg.render(p)), _bits(so.render(p)))
+    for via in (1, 0):
+        sg.set_option("audit_via_queue", via)
+        tg, dg, _ = sg.render_paths(p)
+        to, do, _ = so.render_paths(p)
+        assert np.array_equal(tg, to) and np.array_equal(_bits(dg), _bits(do))
+    sg.set_option("megakernel", 1)
+    assert np.array_equal(_bits(sg.render(p)), _bits(so.render(p)))
+    tri, nodes = _chain_tree(63)              # depth 64
+    with pytest.raises(trace.TraceError, match="depth 64"):
+        hip.scene_create(tri, nodes)

@@ -347,3 +347,28 @@ def test_scene_description_file_builds_the_canned_scene_on_the_host(bunny_small,
     n = m.nodes[1:, 3]
     assert n.max() <= 4 and n[n > 0].sum() == b.tri.shape[0] and not np.array_equal(m.nodes[:20], b.nodes[:20])
     assert render.material_from({"defaults": "p3", "roughness": 0.25}).to18()[10] == np.float32(0.25)
+
+
+def test_old_style_runs_edge_cases():
+    """(a) four run markers in a row would shift an int by 24+ bits (undefined in the reference,
+    hdrloader.cpp:200): refused; (b) decrunch's fallback enters oldDecrunch at pixel 1 with pixel 0 already written
+    (hdrloader.cpp:135-139), so a run marker right there repeats pixel 0 as the reference does."""
+    head = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 1 +X 8\n"
+    px = lambda r, g, b, e: bytes([r, g, b, e])
+    # (b) first byte 2 but second not 2: flat data whose first pixel is (2, 9, 9, 128); then a run of 3, then 4 literals
+    body = px(2, 9, 9, 128) + px(1, 1, 1, 3) + b"".join(px(10 + k, 20, 30, 129) for k in range(4))
+    got = S.hdrLoad(data=head + body)
+    assert got.shape == (1, 8, 3)
+    first = np.array([2, 9, 9], np.float32) / np.float32(256.0)
+    assert np.array_equal(got[0, :4], np.tile(first, (4, 1)))
+    assert np.array_equal(got[0, 4:, 0], (np.arange(10, 14, dtype=np.float32) / np.float32(256.0)) * np.float32(2.0))
+    # a run marker as the very first pixel of a line has nothing to repeat: the line fails, and (like the reference,
+    # hdrloader.cpp:88-89 `if (decrunch(..) == false) break;`) load still returns, with the unread rows left zero
+    assert not S.hdrLoad(data=head + px(1, 1, 1, 2) + px(5, 5, 5, 128) * 8).any()
+    # (a) pixel, then four consecutive run markers (1 copy, 0 << 8, 0 << 16, then the shift by 24)
+    bad = px(7, 7, 7, 128) + px(1, 1, 1, 1) + px(1, 1, 1, 0) + px(1, 1, 1, 0) + px(1, 1, 1, 1) + px(5, 5, 5, 128) * 8
+    assert not S.hdrLoad(data=head + bad).any()
+    # three in a row are still fine: 1 + (1 << 8 capped by the line) copies
+    ok = px(7, 7, 7, 128) + px(1, 1, 1, 1) + px(1, 1, 1, 1)
+    got = S.hdrLoad(data=head + ok)
+    assert np.array_equal(got[0], np.tile(np.float32(7) / np.float32(256.0), (8, 3)))
