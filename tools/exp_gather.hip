@@ -48,6 +48,46 @@ __global__ __launch_bounds__(256) void gather(const f4* __restrict__ table, unsi
       float s = a.x + a.y;
       acc += s;
       idx = mix(idx + __float_as_uint(s)) & mask;
+    } else if (MODE == 4 || MODE == 5 || MODE == 6) { // G adjacent lanes (2, 8, 16) read consecutive 16-B pieces of a run starting at a random record
+      constexpr unsigned G = MODE == 4 ? 2u : (MODE == 5 ? 8u : 16u);
+      unsigned q = __shfl(idx, threadIdx.x & ~(G - 1u), 64);
+      f4 a = table[((size_t)q * 4 + (threadIdx.x & (G - 1u))) & ((size_t)mask * 4 + 3)];
+      float s = a.x + a.y;
+      for (unsigned o = 1; o < G; o <<= 1) s += __shfl_xor(s, o, 64);
+      acc += s;
+      idx = mix(idx + __float_as_uint(s)) & mask;
+    } else if (MODE == 7) { // 3 loads per lane at stride 48 B inside groups of 8 lanes (a leaf's triangles, one per lane: today's g = 8 pattern)
+      unsigned q = __shfl(idx, threadIdx.x & ~7u, 64);
+      const size_t base = ((size_t)q * 4 + (threadIdx.x & 7u) * 3) & ((size_t)mask * 4 + 3);
+      f4 a = table[base], b = table[(base + 1) & ((size_t)mask * 4 + 3)], c = table[(base + 2) & ((size_t)mask * 4 + 3)];
+      float s = a.x + b.y + c.z;
+      for (unsigned o = 1; o < 8; o <<= 1) s += __shfl_xor(s, o, 64);
+      acc += s;
+      idx = mix(idx + __float_as_uint(s)) & mask;
+    } else if (MODE == 8) { // the same 24 pieces read leaf-SoA: load p of lane j = piece p * 8 + j (8 lanes x 16 B contiguous per load)
+      unsigned q = __shfl(idx, threadIdx.x & ~7u, 64);
+      const size_t base = (size_t)q * 4 + (threadIdx.x & 7u), m4 = (size_t)mask * 4 + 3;
+      f4 a = table[base & m4], b = table[(base + 8) & m4], c = table[(base + 16) & m4];
+      float s = a.x + b.y + c.z;
+      for (unsigned o = 1; o < 8; o <<= 1) s += __shfl_xor(s, o, 64);
+      acc += s;
+      idx = mix(idx + __float_as_uint(s)) & mask;
+    } else if (MODE == 9) { // pairs: 3 loads per lane at stride 48 B in groups of 2 (today's g = 2 pattern)
+      unsigned q = __shfl(idx, threadIdx.x & ~1u, 64);
+      const size_t base = ((size_t)q * 4 + (threadIdx.x & 1u) * 3), m4 = (size_t)mask * 4 + 3;
+      f4 a = table[base & m4], b = table[(base + 1) & m4], c = table[(base + 2) & m4];
+      float s = a.x + b.y + c.z;
+      s += __shfl_xor(s, 1, 64);
+      acc += s;
+      idx = mix(idx + __float_as_uint(s)) & mask;
+    } else if (MODE == 10) { // pairs, leaf-SoA with n = 6: piece p of triangle k at p * 6 + k
+      unsigned q = __shfl(idx, threadIdx.x & ~1u, 64);
+      const size_t base = ((size_t)q * 4 + (threadIdx.x & 1u)), m4 = (size_t)mask * 4 + 3;
+      f4 a = table[base & m4], b = table[(base + 6) & m4], c = table[(base + 12) & m4];
+      float s = a.x + b.y + c.z;
+      s += __shfl_xor(s, 1, 64);
+      acc += s;
+      idx = mix(idx + __float_as_uint(s)) & mask;
     } else {
       unsigned i1 = mix(idx + 1) & mask, i2 = mix(idx + 2) & mask, i3 = mix(idx + 3) & mask;
       f4 a = table[(size_t)idx * 4], b = table[(size_t)i1 * 4 + 1], c = table[(size_t)i2 * 4 + 2],
@@ -101,6 +141,13 @@ int main(int argc, char** argv) {
     run<1>("B quad-shared 1x16B", table, nrec - 1, iters, out, blocks, 0.25, 1.0);
     run<2>("C lane-owned 1x16B", table, nrec - 1, iters, out, blocks, 1.0, 1.0);
     run<3>("D lane-owned 4 lines", table, nrec - 1, iters, out, blocks, 4.0, 4.0);
+    run<4>("E pair-shared 1x16B", table, nrec - 1, iters, out, blocks, 0.5, 1.0);
+    run<5>("F oct-shared 1x16B", table, nrec - 1, iters, out, blocks, 0.125, 1.0);
+    run<6>("G 16-shared 1x16B", table, nrec - 1, iters, out, blocks, 0.0625, 1.0);
+    run<7>("H 8 lanes x 3 @48B stride", table, nrec - 1, iters, out, blocks, 1.0, 3.0);
+    run<8>("I 8 lanes x 3 leaf-SoA", table, nrec - 1, iters, out, blocks, 1.0, 3.0);
+    run<9>("J 2 lanes x 3 @48B stride", table, nrec - 1, iters, out, blocks, 1.0, 3.0);
+    run<10>("K 2 lanes x 3 leaf-SoA", table, nrec - 1, iters, out, blocks, 1.0, 3.0);
     hipFree(table);
   }
   return 0;
