@@ -52,6 +52,10 @@ TRACE_ABI = {
     "ezrt_scene_set_sampler": (C.c_int, [C.c_void_p, C.c_int]),
     "ezrt_render": (C.c_int, [C.c_void_p, C.POINTER(EzrtRenderParams), c_float_p]),
     "ezrt_render_device": (C.c_int, [C.c_void_p, C.POINTER(EzrtRenderParams), C.c_void_p, C.c_void_p]),
+    "ezrt_frame_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "ezrt_frame_destroy": (C.c_int, [C.c_void_p]),
+    "ezrt_frame_read": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_float_p]),
+    "ezrt_frame_write": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_float_p]),
     "ezrt_render_paths": (C.c_int, [C.c_void_p, C.POINTER(EzrtRenderParams), c_int32_p, c_float_p, c_float_p]),
     "ezrt_query_hits": (C.c_int, [C.c_void_p, c_float_p, C.c_int, c_int32_p, c_float_p]),
     "ezrt_tonemap": (C.c_int, [c_float_p, C.c_int, c_uint8_p]),

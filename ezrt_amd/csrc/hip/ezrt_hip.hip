@@ -248,25 +248,21 @@ bool same_blocks(const EzrtRenderParams& a, const EzrtRenderParams& b) {
   return a.width == b.width && a.height == b.height && a.x0 == b.x0 && a.y0 == b.y0 && a.x1 == b.x1 && a.y1 == b.y1 &&
          a.tile_w == b.tile_w && a.tile_h == b.tile_h && a.shard_index == b.shard_index && a.shard_count == b.shard_count;
 }
-bool owned_host(const EzrtRenderParams& p, int x, int y) {
-  if (x < p.x0 || x >= p.x1 || y < p.y0 || y >= p.y1) return false;
-  if (p.shard_count <= 1) return true;
-  int tw = p.tile_w > 0 ? p.tile_w : 32, th = p.tile_h > 0 ? p.tile_h : 32;
-  int tiles_x = (p.width + tw - 1) / tw;
-  int tile = (y / th) * tiles_x + (x / tw);
-  return tile % p.shard_count == p.shard_index;
-}
-
-// list of 16x16 pixel blocks holding at least one owned pixel
+// list of 16x16 pixel blocks holding at least one owned pixel: a block is kept iff one of the tiles that overlap
+// (block AND rect) belongs to this shard -- a handful of tile cells per block instead of its 256 pixels
 int build_blocks(EzrtScene* s, const EzrtRenderParams& p, hipStream_t st) {
   if (s->blocks_valid && same_blocks(s->blocks_for, p)) return 0;
   std::vector<int2>& v = s->blocks_host;
   v.clear();
+  const int tw = p.tile_w > 0 ? p.tile_w : 32, th = p.tile_h > 0 ? p.tile_h : 32;
+  const int tiles_x = (p.width + tw - 1) / tw;
   for (int by = (p.y0 / 16) * 16; by < p.y1; by += 16)
     for (int bx = (p.x0 / 16) * 16; bx < p.x1; bx += 16) {
-      bool any = false;
-      for (int y = by; y < by + 16 && !any; y++)
-        for (int x = bx; x < bx + 16 && !any; x++) any = owned_host(p, x, y);
+      const int xa = std::max(bx, p.x0), xb = std::min(bx + 16, p.x1), ya = std::max(by, p.y0), yb = std::min(by + 16, p.y1);
+      if (xa >= xb || ya >= yb) continue;
+      bool any = p.shard_count <= 1;
+      for (int ty = ya / th; ty <= (yb - 1) / th && !any; ty++)
+        for (int tx = xa / tw; tx <= (xb - 1) / tw && !any; tx++) any = (ty * tiles_x + tx) % p.shard_count == p.shard_index;
       if (any) v.push_back(make_int2(bx, by));
     }
   if (!v.empty()) {
@@ -704,6 +700,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
       const bool compact = p->integrator == EZRT_INTEGRATOR_P5_SOBOL; // (compact_state<50>: see PathState)
       g.st_slot = compact ? state(in).s1 : state(in).s2;
       g.slot_comp = compact ? (b == 1 ? 0 : 3) : 3;
+      g.slot_stride = (compact && b == 1) ? 2 : 4;
       g.n_in = pp.qcounts.p + b;
       g.n_slots = (uint32_t)n_slots;
       g.bounce = b;
@@ -1229,6 +1226,37 @@ int ezrt_render(EzrtScene* s, const EzrtRenderParams* p, float* accum) {
   if (rc) return rc;
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(accum, s->accum_tmp.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int ezrt_frame_create(int width, int height, float** frame_dev) {
+  if (!frame_dev || width <= 0 || height <= 0) return fail(EZRT_ERR_INVALID, "bad frame arguments");
+  *frame_dev = nullptr;
+  const size_t bytes = (size_t)width * height * sizeof(float4);
+  float* p = nullptr;
+  HIP_TRY(hipMalloc((void**)&p, bytes));
+  hipError_t e = hipMemset(p, 0, bytes);
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    return fail(EZRT_ERR_DEVICE, "hipMemset failed: %s", hipGetErrorString(e));
+  }
+  *frame_dev = p;
+  return 0;
+}
+int ezrt_frame_destroy(float* frame_dev) {
+  if (frame_dev) HIP_TRY(hipFree(frame_dev));
+  return 0;
+}
+int ezrt_frame_read(const float* frame_dev, int width, int height, float* rgba_host) {
+  if (!frame_dev || !rgba_host || width <= 0 || height <= 0) return fail(EZRT_ERR_INVALID, "bad frame arguments");
+  HIP_TRY(hipDeviceSynchronize()); // whatever stream rendered into it
+  HIP_TRY(hipMemcpy(rgba_host, frame_dev, (size_t)width * height * sizeof(float4), hipMemcpyDeviceToHost));
+  return 0;
+}
+int ezrt_frame_write(float* frame_dev, int width, int height, const float* rgba_host) {
+  if (!frame_dev || !rgba_host || width <= 0 || height <= 0) return fail(EZRT_ERR_INVALID, "bad frame arguments");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(frame_dev, rgba_host, (size_t)width * height * sizeof(float4), hipMemcpyHostToDevice));
   return 0;
 }
 

@@ -34,7 +34,8 @@ struct PathState { // SoA of float4, one slot per live path
   float4* s4; // shadow contribution.xyz, bits(flags)          (integrator 51 only)
   // Integrator 50 (pdf is the constant 1/(2 pi), no RNG state after ray generation, Le0 = the emission of the
   // primary hit's triangle) carries a COMPACT state instead -- the shading stages are bound by streaming this state:
-  //   into stage 1 (history = 1 and Lo = 0 exactly):  s0 = f_r.xyz, cosine   s1 = bits(sample slot), bits(tri0)   24 of 32 B
+  //   into stage 1 (history = 1 and Lo = 0 exactly):  s0 = f_r.xyz, cosine   s1 = float2: bits(sample slot), bits(tri0)   24 B
+  //   (tri0 = the primary hit's triangle if its emission is not all-zero bits, else 0xffffffff)
   //   into stages >= 2:  s0 = history.xyz, cosine   s1 = Lo.xyz, bits(sample slot)   s2 = f_r.xyz, bits(tri0)      48 B
   // (tri0 = the primary hit's triangle; Le0 is re-read from its material at the path's end)
 };
@@ -224,7 +225,12 @@ EZD void shade_load(const WfArgs& a, const uint32_t i, const bool live, ShadeIn&
     if (PASS != 1) ro4 = a.rq_in.o[rslot]; // (only a surface interaction needs the ray origin)
     if (!COMPACT) s3 = a.st_in.s3[ii];
     s0 = a.st_in.s0[ii];
-    s1 = a.st_in.s1[ii];
+    if (COMPACT && STAGE == 1) { // (bits(sample slot), bits(tri0)) only: 8-byte records in the s1 array
+      const float2 q = reinterpret_cast<const float2*>(a.st_in.s1)[ii];
+      s1 = make_float4(q.x, q.y, 0.0f, 0.0f);
+    } else {
+      s1 = a.st_in.s1[ii];
+    }
     if (!COMPACT || STAGE >= 2) s2 = a.st_in.s2[ii];
     if (MIS) {
       s4 = a.st_in.s4[ii];
@@ -297,7 +303,9 @@ EZD bool shade_body(const WfArgs& a, const uint32_t i, bool live, const ShadeIn&
         if (PASS == 1) return true; // surface interaction: shaded in dense waves (shade_hit_kernel)
         shade_point<P5TRI>(sc, h.x, __int_as_float(h.y), mk(ro4.x, ro4.y, ro4.z), rd, hit);
         Le0 = hit.m.emissive;
-        tri0 = (uint32_t)h.x;
+        // compact state: the primary hit's triangle is carried only when its emission has a set bit -- a later stage
+        // then re-reads Le0 from its material, and every other path (all but the light's pixels) skips that gather
+        tri0 = (__float_as_uint(Le0.x) | __float_as_uint(Le0.y) | __float_as_uint(Le0.z)) ? (uint32_t)h.x : 0xffffffffu;
         if (INTEG != EZRT_INTEGRATOR_P5_SOBOL) { // (integrator 50 draws nothing after ray generation: Sobol + CP only)
           // RNG state after the two anti-aliasing draws of ray generation (P5/fsh:315-318, 920-921)
           int x0, y0;
@@ -324,9 +332,12 @@ EZD bool shade_body(const WfArgs& a, const uint32_t i, bool live, const ShadeIn&
         f_r = mk(s2.x, s2.y, s2.z);
         tri0 = __float_as_uint(s2.w);
       }
-      // Le0 = the primary hit's emission (getMaterial: texel 6 of its record), needed when the path ends
-      const float* e = sc.tri_ref + (size_t)tri0 * EZRT_TRI_FLOATS + 18;
-      Le0 = mk(e[0], e[1], e[2]);
+      // Le0 = the primary hit's emission (getMaterial: texel 6 of its record), needed when the path ends; all-zero
+      // bits (tri0 = none) for every non-emissive primary hit
+      if (tri0 != 0xffffffffu) {
+        const float* e = sc.tri_ref + (size_t)tri0 * EZRT_TRI_FLOATS + 18;
+        Le0 = mk(e[0], e[1], e[2]);
+      }
     } else {
       history = mk(s0.x, s0.y, s0.z);
       cosine = s0.w;
@@ -479,7 +490,7 @@ template <bool MIS, int FORM>
 EZD void shade_store(const WfArgs& a, const ShadeOut& o, const uint32_t k) {
   if (FORM == 1) {
     a.st_out.s0[k] = make_float4(o.f_r.x, o.f_r.y, o.f_r.z, o.cosine);
-    a.st_out.s1[k] = make_float4(__uint_as_float(o.sslot), __uint_as_float(o.tri0), 0.0f, 0.0f);
+    reinterpret_cast<float2*>(a.st_out.s1)[k] = make_float2(__uint_as_float(o.sslot), __uint_as_float(o.tri0));
   } else if (FORM == 2) {
     a.st_out.s0[k] = make_float4(o.history.x, o.history.y, o.history.z, o.cosine);
     a.st_out.s1[k] = make_float4(o.Lo.x, o.Lo.y, o.Lo.z, __uint_as_float(o.sslot));
@@ -736,7 +747,8 @@ struct PathLogArgs {
   const int2* hits;      // hit records of the stage's ray queue
   const float4* rq_d;    // its ray directions (.w = 0: slot not shot)
   const float4* st_slot; // the path-state array that holds bits(sample slot) for this stage, and in which component
-  int32_t slot_comp;     //   (general state: s2.w; compact state of integrator 50: s1.x into stage 1, s1.w later)
+  int32_t slot_comp;     //   (general state: s2.w; compact state of integrator 50: float2 s1[i].x into stage 1, s1.w later)
+  int32_t slot_stride;   //   floats per path in that array (4; 2 for the compact state into stage 1)
   const uint32_t* n_in;  // paths in the queue (stage >= 1)
   uint32_t n_slots;      // stage 0: pixel-samples of the chunk
   int32_t bounce;        // stage index b (0 = primary rays)
@@ -756,7 +768,7 @@ __global__ __launch_bounds__(BLOCK) void pathlog_kernel(PathLogArgs a) {
   const uint32_t n = a.bounce == 0 ? a.n_slots : *a.n_in;
   if (i >= n) return;
   const uint32_t sslot = a.bounce == 0 ? queue_to_sample(i, (uint32_t)a.n_blocks, a.scatter, a.scatter_shift)
-                                       : __float_as_uint((&a.st_slot[i].x)[a.slot_comp]);
+                                       : __float_as_uint(reinterpret_cast<const float*>(a.st_slot)[(size_t)i * a.slot_stride + a.slot_comp]);
   int x, y;
   uint32_t frame;
   slot_to_pixel(a.blocks, a.n_blocks, sslot, a.frame_first, x, y, frame);

@@ -9,7 +9,10 @@ handlers of the reference do for a user (P3/main.cpp:596-672), minus the window.
 A camera change only resets the counter: frame 0 ignores the previous frame-buffer content (the
 reference multiplies it by 0), so the buffer is not cleared.  A checkpoint is {frame buffer, frame
 counter, camera, render settings}; resuming from it continues the running mean exactly where it
-stopped -- the result is bit-identical to an uninterrupted run (tests/test_progressive.py)."""
+stopped -- the result is bit-identical to an uninterrupted run (tests/test_progressive.py).
+
+lastFrame lives on the device (ezrt_frame_create, like the GL texture it replaces): step() only enqueues
+ezrt_render_device, and the frame crosses PCIe when `accum` is read (present / save), not once per display() call."""
 import json
 
 import numpy as np
@@ -27,17 +30,21 @@ class ProgressiveRenderer:
         self.env_clamp = env_clamp
         self.rotatAngle, self.upAngle, self.r = float(rotatAngle), float(upAngle), float(r)
         self.frameCounter = 0
-        self.accum = np.zeros((self.height, self.width, 4), np.float32)   # lastFrame
+        self.frame = gpu_scene._tl.frame(self.width, self.height)   # lastFrame, device-resident
+
+    @property
+    def accum(self):
+        """lastFrame as a host array (a synchronising read-back)."""
+        return self.frame.read()
 
     # ---- the reference's callbacks
     def step(self, n=1):
-        """n more samples per pixel (n calls of display())."""
+        """n more samples per pixel (n calls of display()); asynchronous, lastFrame stays on the device."""
         eye, cam = S.camera(self.rotatAngle, self.upAngle, self.r)
         p = trace.make_params(self.width, self.height, eye, cam, self.integrator, self.max_bounce, spp=int(n),
                               frame0=self.frameCounter, env_clamp=self.env_clamp)
-        self.scene.render(p, self.accum)
+        self.scene.render_device(p, self.frame.ptr)
         self.frameCounter += int(n)
-        return self.accum
 
     def drag(self, dx, dy):
         self.frameCounter = 0
@@ -65,8 +72,8 @@ class ProgressiveRenderer:
             accum = np.ascontiguousarray(z["accum"], np.float32)
         fc = st.pop("frameCounter")
         self = cls(gpu_scene, **st)
-        if accum.shape != self.accum.shape:
+        if accum.shape != (self.height, self.width, 4):
             raise ValueError("checkpoint frame buffer %s does not match %dx%d" % (accum.shape, self.width, self.height))
-        self.accum = accum
+        self.frame.write(accum)
         self.frameCounter = int(fc)
         return self

@@ -132,9 +132,47 @@ class Scene:
         return dict(zip(("n_tri", "n_nodes", "depth", "n_leaves", "max_leaf", "device_bytes"), [int(x) for x in out]))
 
 
+class Frame:
+    """A device-resident lastFrame (ezrt_frame_*): RGBA32F [height, width, 4], zeroed."""
+
+    def __init__(self, tl, width, height):
+        self._tl = tl
+        self.width, self.height = int(width), int(height)
+        h = C.c_void_p()
+        if tl.lib.ezrt_frame_create(self.width, self.height, C.byref(h)) != 0:
+            raise TraceError(tl.lib.ezrt_last_error().decode())
+        self.ptr = h.value
+
+    def read(self):
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        if self._tl.lib.ezrt_frame_read(self.ptr, self.width, self.height, _fp(out)) != 0:
+            raise TraceError(self._tl.lib.ezrt_last_error().decode())
+        return out
+
+    def write(self, rgba):
+        a = np.ascontiguousarray(rgba, np.float32)
+        assert a.shape == (self.height, self.width, 4)
+        if self._tl.lib.ezrt_frame_write(self.ptr, self.width, self.height, _fp(a)) != 0:
+            raise TraceError(self._tl.lib.ezrt_last_error().decode())
+
+    def close(self):
+        if self.ptr:
+            self._tl.lib.ezrt_frame_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class TraceLib:
     def __init__(self, cdll):
         self.lib = cdll
+
+    def frame(self, width, height):
+        return Frame(self, width, height)
 
     def backend(self):
         return self.lib.ezrt_backend().decode()

@@ -117,6 +117,14 @@ int ezrt_render(EzrtScene* s, const EzrtRenderParams* p, float* accum_rgba);
  * concurrent streams (or devices, include/ezrt_mgpu.h) take one scene each. */
 int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_rgba_dev, void* stream);
 
+/* A device-resident lastFrame for hosts without their own device allocator (the GL texture of P5/main.cpp:926-929:
+ * created once, accumulated into by every display() call, read back only to present or save).  frame_create returns a
+ * zeroed RGBA32F [height][width][4] buffer on the current device; read / write are the synchronising host copies. */
+int ezrt_frame_create(int width, int height, float** frame_dev);
+int ezrt_frame_destroy(float* frame_dev);
+int ezrt_frame_read(const float* frame_dev, int width, int height, float* rgba_host);
+int ezrt_frame_write(float* frame_dev, int width, int height, const float* rgba_host);
+
 /* Parity audit: render exactly one frame (p->frame0, spp ignored) and report
  * for every pixel of the rect and every ray slot of its path the hit triangle
  * id (-1 = miss, -2 = ray not shot) and distance.  Slots: 0 = primary; for

@@ -1011,6 +1011,27 @@ int ezrt_render(EzrtScene* s, const EzrtRenderParams* p, float* accum) {
   return ezrt_render_device(s, p, accum, NULL);
 }
 
+/* "device" frames are host memory here */
+int ezrt_frame_create(int width, int height, float** frame_dev) {
+  if (!frame_dev || width <= 0 || height <= 0) return fail(EZRT_ERR_INVALID, "bad frame arguments");
+  *frame_dev = (float*)calloc((size_t)width * height * 4, sizeof(float));
+  return *frame_dev ? 0 : fail(EZRT_ERR_NOMEM, "out of memory");
+}
+int ezrt_frame_destroy(float* frame_dev) {
+  free(frame_dev);
+  return 0;
+}
+int ezrt_frame_read(const float* frame_dev, int width, int height, float* rgba_host) {
+  if (!frame_dev || !rgba_host || width <= 0 || height <= 0) return fail(EZRT_ERR_INVALID, "bad frame arguments");
+  memcpy(rgba_host, frame_dev, (size_t)width * height * 16);
+  return 0;
+}
+int ezrt_frame_write(float* frame_dev, int width, int height, const float* rgba_host) {
+  if (!frame_dev || !rgba_host || width <= 0 || height <= 0) return fail(EZRT_ERR_INVALID, "bad frame arguments");
+  memcpy(frame_dev, rgba_host, (size_t)width * height * 16);
+  return 0;
+}
+
 int ezrt_render_paths(EzrtScene* s, const EzrtRenderParams* p, int32_t* tri_id, float* t_hit, float* colour) {
   if (!s || !tri_id || !t_hit) return fail(EZRT_ERR_INVALID, "NULL argument");
   int rc = validate_params(p);
