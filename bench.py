@@ -339,6 +339,18 @@ def main():
                                                         "ms_per_step": round(d2 / 5 * 1e3, 4),
                                                         "rays_per_step": int(sc.counters()["rays"] / 5)}
 
+            # the host-buffer entry point (ezrt_render: lastFrame crosses PCIe in and out on every call) -- never `value`
+            host_acc = np.zeros((H, W, 4), np.float32)
+            sc.render(p, host_acc)
+            sc.counters_reset()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                sc.render(p, host_acc)
+            dh = time.perf_counter() - t1
+            out["config"]["host_buffer_entry_ezrt_render"] = {"Mrays_s_pcie_inclusive": round(sc.counters()["rays"] / dh / 1e6, 2),
+                                                              "ms_per_step": round(dh / 5 * 1e3, 4),
+                                                              "frame_bytes_each_way": int(H * W * 16)}
+
         # ---- CPU baseline: the oracle (a port, not the reference binary) on a bounded sample
         if args.cpu_seconds > 0:
             from ezrt_amd import _abi

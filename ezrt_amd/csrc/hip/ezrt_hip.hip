@@ -1030,7 +1030,11 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
           memcpy(&v[6][k], &rf, 4);
         }
         float4* o = &inner4[(size_t)number[q] * N4_FLOAT4];
-        for (int c = 0; c < 7; c++) o[c] = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+        for (int c = 0; c < 3; c++) { // rows: see EZRT_SLAB_SELECT in ezrt_traceq4.h
+          o[N4_ROW_AA + c] = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+          o[N4_ROW_BB + c] = make_float4(v[3 + c][0], v[3 + c][1], v[3 + c][2], v[3 + c][3]);
+        }
+        o[N4_ROW_REF] = make_float4(v[6][0], v[6][1], v[6][2], v[6][3]);
       }
     }
   }

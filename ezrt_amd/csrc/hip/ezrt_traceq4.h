@@ -35,6 +35,22 @@
 
 namespace ezd {
 
+// EZRT_SLAB_SELECT = 1: the near / far plane of each axis is SELECTED by the sign of 1/direction -- through the address
+// of the 16-byte row that is loaded -- instead of computed with v_min / v_max of both products.  For a tame ray the
+// two are the same numbers: AA <= BB componentwise, fl(x - S) and fl(. * inv) are monotone, so with inv >= 0 the AA
+// product is the smaller one and with inv < 0 the BB product (equal products: either; +-0 only ever feed
+// comparisons; NaN rows of unused slots stay NaN).  v_min/v_max/v_min3 issue at about half the rate of v_mul/v_sub on
+// gfx950 (profiles/r2/valu_issue_microbench.txt): 24 of them per record become 12 integer address operations.
+// Row order of a record, so that the BB row of an axis lies 64 bytes after its AA row:
+//   select: AAx AAy AAz ref BBx BBy BBz (pad)      min/max: AAx AAy AAz BBx BBy BBz ref (pad)
+#ifndef EZRT_SLAB_SELECT
+#define EZRT_SLAB_SELECT 1
+#endif
+#if EZRT_SLAB_SELECT
+constexpr int N4_ROW_AA = 0, N4_ROW_BB = 4, N4_ROW_REF = 3;
+#else
+constexpr int N4_ROW_AA = 0, N4_ROW_BB = 3, N4_ROW_REF = 6;
+#endif
 constexpr uint32_t REF_EMPTY = 0xfffffffdu; // unused slot of a 4-wide record
 constexpr int N4_FLOAT4 = 8;                // record stride in HBM, float4s (7 used)
 constexpr int N4_LDS_DWORDS = 28;           // record stride in LDS: 112 B; 28 r mod 64 hits 16 distinct bank quads
@@ -54,12 +70,13 @@ __global__ void inner4_rel_kernel(const float4* in, int n, float sx, float sy, f
   const float4* r = in + (size_t)i * N4_FLOAT4;
   float4* o = out + (size_t)i * N4_FLOAT4;
   const float s[3] = {sx, sy, sz};
-  for (int k = 0; k < 6; k++) {
-    const float4 v = r[k];
-    const float c = s[k % 3];
-    o[k] = make_float4(v.x - c, v.y - c, v.z - c, v.w - c);
+  for (int k = 0; k < 3; k++) {
+    const float4 v = r[N4_ROW_AA + k], w = r[N4_ROW_BB + k];
+    const float c = s[k];
+    o[N4_ROW_AA + k] = make_float4(v.x - c, v.y - c, v.z - c, v.w - c);
+    o[N4_ROW_BB + k] = make_float4(w.x - c, w.y - c, w.z - c, w.w - c);
   }
-  o[6] = r[6];
+  o[N4_ROW_REF] = r[N4_ROW_REF];
   o[7] = r[7];
 }
 
@@ -265,10 +282,57 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
       dbg_busy_lanes += (uint32_t)__popcll(ballot(ref < REF_DONE));
     }
     if (at_inner) {
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      typedef __attribute__((address_space(3))) const v4f lds_v4f;
+#if EZRT_SLAB_SELECT
+      typedef __attribute__((address_space(3))) const char lds_char;
+      // byte offset of the NEAR row of each axis inside a record: 0 (AA) for inv >= 0, 64 (BB) for inv < 0
+      const uint32_t kx = (__float_as_uint(inv.x) >> 31) << 6, ky = (__float_as_uint(inv.y) >> 31) << 6,
+                     kz = (__float_as_uint(inv.z) >> 31) << 6;
+      v4f nx, ny, nz, fx, fy, fz, rfv;
+      if (ref < (uint32_t)A.lds_nodes4) { // top of the tree: staged in LDS
+        lds_char* lb = (lds_char*)lds_nodes + ref * (uint32_t)(N4_LDS_DWORDS * 4);
+        nx = *(lds_v4f*)(lb + kx);
+        ny = *(lds_v4f*)(lb + 16u + ky);
+        nz = *(lds_v4f*)(lb + 32u + kz);
+        fx = *(lds_v4f*)(lb + 64u - kx);
+        fy = *(lds_v4f*)(lb + 80u - ky);
+        fz = *(lds_v4f*)(lb + 96u - kz);
+        rfv = *(lds_v4f*)(lb + 48u);
+      } else {
+        // (32-bit offsets from the uniform table pointer: global_load with an SGPR base and one VGPR offset each,
+        // no 64-bit address arithmetic; the table is < 2^32 bytes: n_inner4 < 2^24 records of 128 B)
+        const char* tab = reinterpret_cast<const char*>(inner);
+        const uint32_t roff = ref * (uint32_t)(N4_FLOAT4 * 16);
+        nx = *reinterpret_cast<const v4f*>(tab + (uint32_t)(roff + kx));
+        ny = *reinterpret_cast<const v4f*>(tab + (uint32_t)(roff + ky + 16u));
+        nz = *reinterpret_cast<const v4f*>(tab + (uint32_t)(roff + kz + 32u));
+        fx = *reinterpret_cast<const v4f*>(tab + (uint32_t)(roff + 64u - kx));
+        fy = *reinterpret_cast<const v4f*>(tab + (uint32_t)(roff + 80u - ky));
+        fz = *reinterpret_cast<const v4f*>(tab + (uint32_t)(roff + 96u - kz));
+        rfv = *reinterpret_cast<const v4f*>(tab + (uint32_t)(roff + 48u));
+      }
+      const float4 rf = make_float4(rfv.x, rfv.y, rfv.z, rfv.w);
+      auto slab = [&](float nxk, float nyk, float nzk, float fxk, float fyk, float fzk) -> bool {
+        float t0x, t0y, t0z, t1x, t1y, t1z;
+        if (REL) { // boxes already translated by the common origin
+          t0x = nxk * inv.x, t0y = nyk * inv.y, t0z = nzk * inv.z;
+          t1x = fxk * inv.x, t1y = fyk * inv.y, t1z = fzk * inv.z;
+        } else {
+          t0x = (nxk - S.x) * inv.x, t0y = (nyk - S.y) * inv.y, t0z = (nzk - S.z) * inv.z;
+          t1x = (fxk - S.x) * inv.x, t1y = (fyk - S.y) * inv.y, t1z = (fzk - S.z) * inv.z;
+        }
+        const float t1 = hw_min3(t1x, t1y, t1z);
+        const float t0 = hw_max3(t0x, t0y, t0z);
+        return (t1 >= t0) && (t1 > 0.0f); // == hitAABB(..) > 0
+      };
+      const bool h0 = slab(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x);
+      const bool h1 = slab(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y);
+      const bool h2 = slab(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z);
+      const bool h3 = slab(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w);
+#else
       float4 ax, ay, az, bx, by, bz, rf;
       if (ref < (uint32_t)A.lds_nodes4) { // top of the tree: staged in LDS
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        typedef __attribute__((address_space(3))) const v4f lds_v4f;
         lds_v4f* r = (lds_v4f*)(lds_nodes + ref * 7u);
         const v4f w0 = r[0], w1 = r[1], w2 = r[2], w3 = r[3], w4 = r[4], w5 = r[5], w6 = r[6];
         ax = make_float4(w0.x, w0.y, w0.z, w0.w);
@@ -305,6 +369,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
       const bool h1 = slab(ax.y, ay.y, az.y, bx.y, by.y, bz.y);
       const bool h2 = slab(ax.z, ay.z, az.z, bx.z, by.z, bz.z);
       const bool h3 = slab(ax.w, ay.w, az.w, bx.w, by.w, bz.w);
+#endif
       const uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z),
                      r3 = __float_as_uint(rf.w);
       // visit the hit slots in ascending order: continue with the lowest, push the others highest-first
