@@ -77,6 +77,37 @@ constexpr bool integ_mis() { return INTEG == EZRT_INTEGRATOR_P5_MIS || INTEG == 
 template <int INTEG>
 constexpr bool integ_aniso_is() { return INTEG == EZRT_INTEGRATOR_P5_MIS_ANISO; }
 
+// Exact unsigned division by a launch-invariant divisor (Granlund-Montgomery, round-up form): with L = ceil(log2 d)
+// and m = floor(2^32 (2^L - d) / d) + 1,  floor(n / d) = (((n - t) >> 1) + t) >> (L - 1),  t = mulhi(m, n),  for every
+// 32-bit n.  The queue <-> sample-slot <-> pixel maps divide by the number of 16x16 blocks / of queue granules, values
+// only known at launch: the compiler's 32-bit division is ~30 instructions, and ray generation runs it three times
+// per sample (it was VALU-bound on them).  tests/test_host_scene.py checks the host twin over the divisors' range.
+struct FastDiv {
+  uint32_t d, m, s; // s = L - 1; d == 1: m = 0 and the quotient is n
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d ? d : 1u;
+  f.m = 0u;
+  f.s = 0u;
+  if (f.d > 1u) {
+    uint32_t L = 0;
+    while ((1ull << L) < f.d) L++;
+    f.m = (uint32_t)((((1ull << L) - f.d) << 32) / f.d) + 1u;
+    f.s = L - 1u;
+  }
+  return f;
+}
+__host__ __device__ inline uint32_t fastdiv(uint32_t n, const FastDiv& f) {
+  if (f.d == 1u) return n;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t t = __umulhi(f.m, n);
+#else
+  const uint32_t t = (uint32_t)(((unsigned long long)f.m * n) >> 32);
+#endif
+  return (((n - t) >> 1) + t) >> f.s;
+}
+
 constexpr uint32_t LEAF_BIT = 0x80000000u;
 
 struct Counters { // per-thread, registers

@@ -566,6 +566,8 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     while (m > 1u && gcd(m, n_sub) != 1u) m += 2u;
     a.scatter = m % n_sub ? m % n_sub : 1u;
   }
+  a.div_blocks = make_fastdiv((uint32_t)nb);
+  a.div_sub = make_fastdiv(((uint32_t)nb * 256u) >> a.scatter_shift);
   HIP_TRY(pp.sobol_tab.ensure((size_t)nf * 16));
   a.sobol_tab = pp.sobol_tab.p;
   a.sobol_out = pp.sobol_tab.p;
@@ -710,6 +712,8 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
       g.frame_first = frame_first;
       g.scatter = a.scatter;
       g.scatter_shift = a.scatter_shift;
+      g.div_blocks = a.div_blocks;
+      g.div_sub = a.div_sub;
       g.width = p->width;
       g.log_slots = 1 + 2 * p->max_bounce;
       g.log_tri = plog->tri;
@@ -807,6 +811,8 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     memset(&g, 0, sizeof g);
     g.blocks = s->blocks.p;
     g.n_blocks = nb;
+    g.div_blocks = a.div_blocks;
+    g.div_sub = a.div_sub;
     g.frame_first = frame_first;
     g.width = p->width;
     g.log_colour = plog->colour;
@@ -1513,8 +1519,22 @@ int ezrt_scene_stats(EzrtScene* s, int64_t out[6]) {
 }
 
 int ezrt_debug_math(int op, const float* a, const float* b, int n, float* out) {
-  if (!a || !out || n < 0 || op < 0 || op > 16) return fail(EZRT_ERR_INVALID, "bad argument");
+  if (!a || !out || n < 0 || op < 0 || op > 17) return fail(EZRT_ERR_INVALID, "bad argument");
   if (n == 0) return 0;
+  if (op == 17) { // floor(bits(a[i]) / bits(b[0])) through the kernels' FastDiv
+    uint32_t d = 0;
+    if (!b) return fail(EZRT_ERR_INVALID, "bad argument");
+    memcpy(&d, b, 4);
+    if (d == 0) return fail(EZRT_ERR_INVALID, "division by zero");
+    DevBuf<float> da, dout;
+    HIP_TRY(da.ensure((size_t)n));
+    HIP_TRY(dout.ensure((size_t)n));
+    HIP_TRY(hipMemcpy(da.p, a, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(fastdiv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, da.p, make_fastdiv(d), n, dout.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+  }
   // ops 10-12 (intersector audit): a = n rays of 6 floats, b = n boxes of 6 / triangles of 9 floats;
   // ops 13-16 (integrator 52's sampler): a = n x 6, b = n x 6 material parameters
   const size_t wa = op >= 10 ? 6 : 1, wb = op == 11 ? 9 : (op >= 10 ? 6 : 1);

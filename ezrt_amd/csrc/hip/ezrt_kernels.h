@@ -349,6 +349,13 @@ __global__ __launch_bounds__(BLOCK) void query_kernel(QueryArgs a) {
   }
 }
 
+// ezrt_debug_math op 17: the launch-invariant division of the queue maps (FastDiv), bits in / bits out
+__global__ void fastdiv_kernel(const float* a, FastDiv f, int n, float* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = __uint_as_float(fastdiv(__float_as_uint(a[i]), f));
+}
+
 __global__ void math_kernel(int op, const float* a, const float* b, int n, float* out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

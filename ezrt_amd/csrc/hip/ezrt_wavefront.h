@@ -62,15 +62,17 @@ struct WfArgs {
   uint32_t n_frames;       // frames of the chunk
   uint32_t* defer_list;    // split shading: per workgroup of shade_miss_kernel, the paths with a surface interaction
   uint32_t* defer_count;   // ... and how many; shaded by the same workgroup index of shade_hit_kernel
+  FastDiv div_blocks;      // division by n_blocks
+  FastDiv div_sub;         // division by the queue granules per frame, (n_blocks * 256) >> scatter_shift
   uint32_t scatter;        // queue order of the primary rays: see queue_to_sample (1 = identity)
   uint32_t scatter_shift;  // scattered granule = 1 << scatter_shift slots (6: 8x8 sub-block, 8: 16x16 block, 5: 8x4 pixels)
 };
 
-EZD void slot_to_pixel(const int2* blocks, int n_blocks, uint32_t slot, uint32_t frame_first, int& x, int& y,
+EZD void slot_to_pixel(const int2* blocks, const FastDiv& n_blocks, uint32_t slot, uint32_t frame_first, int& x, int& y,
                        uint32_t& frame) {
   uint32_t tid = slot & 255u;
   uint32_t b = slot >> 8;
-  uint32_t blk = b % (uint32_t)n_blocks, fk = b / (uint32_t)n_blocks;
+  const uint32_t fk = fastdiv(b, n_blocks), blk = b - fk * n_blocks.d;
   int2 org = blocks[blk];
   uint32_t wave = tid >> 6, lane = tid & 63u;
   x = org.x + (int)((wave & 1u) * 8u + (lane & 7u));
@@ -84,12 +86,12 @@ EZD void slot_to_pixel(const int2* blocks, int n_blocks, uint32_t slot, uint32_t
 // that drew the expensive ones.  So the 8x8 sub-blocks of a frame are visited in a scattered
 // order, sub-block (r * scatter) mod n_sub at position r (scatter ~ 2531, coprime to n_sub): a pool is four
 // sub-blocks from distant parts of the image and every pool costs about the same.
-EZD uint32_t queue_to_sample(uint32_t qslot, uint32_t n_blocks, uint32_t scatter, uint32_t sh = 6u) {
-  const uint32_t n_sub = (n_blocks * 256u) >> sh; // granules of 1 << sh slots per frame
+EZD uint32_t queue_to_sample(uint32_t qslot, const FastDiv& n_sub_div, uint32_t scatter, uint32_t sh = 6u) {
+  const uint32_t n_sub = n_sub_div.d; // granules of 1 << sh slots per frame = (n_blocks * 256) >> sh
   const uint32_t q = qslot >> sh;
-  const uint32_t fk = q / n_sub, r = q - fk * n_sub;
-  const uint32_t r2 = (r * scatter) % n_sub; // 32-bit: the host keeps n_sub <= 2^20 and scatter < 2^12 here (a 64-bit
-                                             // modulo is a software loop: it was a third of raygen and of the primary shading)
+  const uint32_t fk = fastdiv(q, n_sub_div), r = q - fk * n_sub;
+  const uint32_t p = r * scatter; // 32-bit: the host keeps n_sub <= 2^20 and scatter < 2^12 here
+  const uint32_t r2 = p - fastdiv(p, n_sub_div) * n_sub;
   return ((fk * n_sub + r2) << sh) | (qslot & ((1u << sh) - 1u));
 }
 
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(BLOCK) void raygen_kernel(WfArgs a) {
       a.sobol_out[k] = sobol(k & 15u, gray_code(a.frame_first + (k >> 4) + 1u));
   int x, y;
   uint32_t frame;
-  slot_to_pixel(a.blocks, a.n_blocks, queue_to_sample(slot, (uint32_t)a.n_blocks, a.scatter, a.scatter_shift), a.frame_first, x, y, frame);
+  slot_to_pixel(a.blocks, a.div_blocks, queue_to_sample(slot, a.div_sub, a.scatter, a.scatter_shift), a.frame_first, x, y, frame);
   const EzrtRenderParams& p = a.p;
   if (!pixel_owned(p, x, y)) {
     a.rq_out.d[slot] = make_float4(0, 0, 0, 0.0f);
@@ -291,7 +293,7 @@ EZD bool shade_body(const WfArgs& a, const uint32_t i, bool live, const ShadeIn&
   f3 colour = mk(0, 0, 0);
   const f3 rd = mk(rd4.x, rd4.y, rd4.z);
   if (B0) {
-    sslot = queue_to_sample(i, (uint32_t)a.n_blocks, a.scatter, a.scatter_shift);
+    sslot = queue_to_sample(i, a.div_sub, a.scatter, a.scatter_shift);
     if (rd4.w == 0.0f) {
       live = false; // pixel not owned by this shard
     } else {
@@ -310,7 +312,7 @@ EZD bool shade_body(const WfArgs& a, const uint32_t i, bool live, const ShadeIn&
           // RNG state after the two anti-aliasing draws of ray generation (P5/fsh:315-318, 920-921)
           int x0, y0;
           uint32_t f0;
-          slot_to_pixel(a.blocks, a.n_blocks, sslot, a.frame_first, x0, y0, f0);
+          slot_to_pixel(a.blocks, a.div_blocks, sslot, a.frame_first, x0, y0, f0);
           seed = ((uint32_t)x0 * 1973u + (uint32_t)y0 * 9277u + f0 * 26699u) | 1u;
           wang_hash(seed);
           wang_hash(seed);
@@ -394,7 +396,7 @@ EZD bool shade_body(const WfArgs& a, const uint32_t i, bool live, const ShadeIn&
     // ---- start bounce b (loop body of pathTracing*, P5/fsh:767-804 / 815-887)
     int x, y;
     uint32_t frame;
-    slot_to_pixel(a.blocks, a.n_blocks, sslot, a.frame_first, x, y, frame);
+    slot_to_pixel(a.blocks, a.div_blocks, sslot, a.frame_first, x, y, frame);
     const f3 V = -hit.viewDir, N = hit.N;
     constexpr bool ANISO_IS = integ_aniso_is<INTEG>();
     f3 X = mk(0, 0, 0), Y = mk(0, 0, 0);
@@ -755,6 +757,7 @@ struct PathLogArgs {
   int32_t mis;           // 1: two rays per path (2i = shadow, 2i + 1 = bounce)
   const int2* blocks;
   int32_t n_blocks;
+  FastDiv div_blocks, div_sub;
   uint32_t frame_first;
   uint32_t scatter, scatter_shift;
   int32_t width, log_slots;
@@ -767,11 +770,11 @@ __global__ __launch_bounds__(BLOCK) void pathlog_kernel(PathLogArgs a) {
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   const uint32_t n = a.bounce == 0 ? a.n_slots : *a.n_in;
   if (i >= n) return;
-  const uint32_t sslot = a.bounce == 0 ? queue_to_sample(i, (uint32_t)a.n_blocks, a.scatter, a.scatter_shift)
+  const uint32_t sslot = a.bounce == 0 ? queue_to_sample(i, a.div_sub, a.scatter, a.scatter_shift)
                                        : __float_as_uint(reinterpret_cast<const float*>(a.st_slot)[(size_t)i * a.slot_stride + a.slot_comp]);
   int x, y;
   uint32_t frame;
-  slot_to_pixel(a.blocks, a.n_blocks, sslot, a.frame_first, x, y, frame);
+  slot_to_pixel(a.blocks, a.div_blocks, sslot, a.frame_first, x, y, frame);
   if (frame != a.frame_first) return; // the log holds one frame
   const size_t pix = (size_t)y * a.width + x;
   auto put = [&](int slot, uint32_t r) {
@@ -798,7 +801,7 @@ __global__ __launch_bounds__(BLOCK) void pathcolour_kernel(PathLogArgs a, EzrtRe
   if (sslot >= (uint32_t)a.n_blocks * 256u) return;
   int x, y;
   uint32_t frame;
-  slot_to_pixel(a.blocks, a.n_blocks, sslot, a.frame_first, x, y, frame);
+  slot_to_pixel(a.blocks, a.div_blocks, sslot, a.frame_first, x, y, frame);
   if (!pixel_owned(p, x, y)) return;
   const float4 c = a.samples[sslot];
   const size_t pix = (size_t)y * a.width + x;

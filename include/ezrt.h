@@ -172,7 +172,8 @@ int ezrt_scene_stats(EzrtScene* s, int64_t out[6]);
  * float of uint bits(a).  Ops 10-12 audit the intersector (a = n rays of 6 floats, b = n boxes of 6 / triangles of
  * 9 floats); ops 13-16 audit integrator 52's sampler in the frame N = (0,0,1) (b = n x (roughness, anisotropic,
  * metallic, clearcoat, clearcoatGloss, -)): 13: a = n x (V, L) -> its pdf; 14/15/16: a = n x (xi1, xi2, xi3, V)
- * -> x / y / z of the sampled direction. */
+ * -> x / y / z of the sampled direction.  Op 17: out bits = floor(bits(a[i]) / bits(b[0])), 32-bit unsigned, computed
+ * the way the kernels divide by launch-invariant counts (exact for every operand). */
 int ezrt_debug_math(int op, const float* a, const float* b, int n, float* out);
 
 const char* ezrt_last_error(void);

@@ -1184,6 +1184,19 @@ int ezrt_debug_math(int op, const float* a, const float* b, int n, float* out) {
     }
     return 0;
   }
+  if (op == 17) { /* floor(bits(a[i]) / bits(b[0])): what the kernels' invariant-divisor form must return */
+    uint32_t d = 0;
+    if (!b) return fail(EZRT_ERR_INVALID, "NULL argument");
+    memcpy(&d, b, 4);
+    if (d == 0) return fail(EZRT_ERR_INVALID, "division by zero");
+    for (int i = 0; i < n; i++) {
+      uint32_t x, q;
+      memcpy(&x, a + i, 4);
+      q = x / d;
+      memcpy(out + i, &q, 4);
+    }
+    return 0;
+  }
   if (op >= 13 && op <= 16) { /* f4 audit in the frame N = (0,0,1), X/Y = getTangent(N).  b = n x (roughness,
                                * anisotropic, metallic, clearcoat, clearcoatGloss, -).  13: a = n x (V, L) ->
                                * brdf_pdf_aniso; 14/15/16: a = n x (xi1, xi2, xi3, V) -> sample_brdf_aniso .x/.y/.z */

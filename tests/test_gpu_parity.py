@@ -380,3 +380,21 @@ def test_deepest_supported_tree_renders_and_deeper_ones_are_refused_at_create(hi
     tri, nodes = _chain_tree(63)              # depth 64
     with pytest.raises(trace.TraceError, match="depth 64"):
         hip.scene_create(tri, nodes)
+
+
+@pytest.mark.gpu
+def test_invariant_divisor_division_is_exact(hip, oracle):
+    """FastDiv (ezrt_device.h): the queue <-> sample slot <-> pixel maps divide by launch-time counts with a multiply
+    and two shifts; must equal n / d for EVERY 32-bit n."""
+    rng = np.random.default_rng(3)
+    edge = np.array([0, 1, 2, 3, 0x7fffffff, 0x80000000, 0x80000001, 0xfffffffe, 0xffffffff], np.uint32)
+    for d in [1, 2, 3, 5, 7, 255, 256, 257, 1000, 1024, 4096, 4097, 65535, 65536, 65537, (1 << 20) - 1, 1 << 20, (1 << 20) + 1,
+              0x7fffffff, 0x80000000, 0x80000001, 0xffffffff] + [int(x) for x in rng.integers(1, 1 << 22, 40)]:
+        n = np.concatenate([edge, rng.integers(0, 1 << 32, 50_000, dtype=np.uint64).astype(np.uint32),
+                            (np.arange(0, 3000, dtype=np.uint64) * d).astype(np.uint32),          # multiples of d and their neighbours
+                            ((np.arange(1, 3000, dtype=np.uint64) * d - 1) & 0xffffffff).astype(np.uint32)])
+        b = np.zeros(n.size, np.uint32)
+        b[0] = d
+        got = hip.debug_math(17, n.view(np.float32), b.view(np.float32), n=n.size).view(np.uint32)
+        assert np.array_equal(got, n // np.uint32(d)), d
+        assert np.array_equal(oracle.debug_math(17, n.view(np.float32), b.view(np.float32), n=n.size).view(np.uint32), got)
