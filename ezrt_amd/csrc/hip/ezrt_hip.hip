@@ -77,7 +77,9 @@ struct Tuning {
   int static_pct = 50;     // share of a trace queue dealt statically to the waves, percent (0: one pool each)
   int refill_min = 24;     // free lanes a wave waits for before it runs its refill code (publish results, adopt the
                            // prefetched ray, prefetch the next): wave-wide code for per-lane events, so batch it (+9 %)
-  int split_shade = 2;     // leaving paths and surface interactions shaded by two kernels: 1 from bounce 1 on, 2 always
+  int split_shade = 3;     // leaving paths and surface interactions shaded by two kernels: 1 from bounce 1 on, 2 always,
+                           // 3 for the primary stage and bounce 1 only (the small late stages run the fused kernel: one
+                           // launch less each, +0.6 %)
   int rel_boxes = 1;       // primary rays traverse boxes already translated by the eye
   int steal = 1;           // intra-wave work stealing in traceq_kernel (+ a redo launch for exact ties)
   int wide4 = 1;           // traceq4_kernel (4-wide collapse of the tree, ezrt_traceq4.h) for the timed stages; 0: the
@@ -106,7 +108,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"lds_nodes", &Tuning::lds_nodes, 0, 1 << 24},
                               {"steal", &Tuning::steal, 0, 1},
                               {"rel_boxes", &Tuning::rel_boxes, 0, 1},
-                              {"split_shade", &Tuning::split_shade, 0, 2},
+                              {"split_shade", &Tuning::split_shade, 0, 3},
                               {"refill_min", &Tuning::refill_min, 1, 64},
                               {"static_pct", &Tuning::static_pct, 0, 95},
                               {"pipes", &Tuning::pipes, 1, 2},
@@ -733,7 +735,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     a.bounce = b;
     a.defer_list = pp.defer_list.p;
     a.defer_count = pp.defer_count.p;
-    if ((b >= 1 && tu.split_shade) || tu.split_shade >= 2)
+    if (tu.split_shade == 3 ? b <= 1 : ((b >= 1 && tu.split_shade) || tu.split_shade >= 2))
       launch_shade_split(a, full, dim3(shade_grid), dim3(shade_grid), st);
     else launch_shade(a, full, dim3(shade_grid), st);
     if (debug_stages) { // diagnostic only: per-stage queue sizes and counters (synchronises)

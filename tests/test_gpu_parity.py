@@ -262,7 +262,7 @@ def test_schedule_knobs_never_change_results(hip, bunny_small):
                      {"leaf_threshold": 64}, {"pool_max": 8}, {"pool_div": 16, "pool_max": 2048}, {"trace_wps": 4},
                      {"trace_wps": 5}, {"trace_wps": 8}, {"lds_nodes": 0}, {"lds_nodes": 7}, {"steal": 0},
                      {"scatter": 0}, {"scatter": 5}, {"scatter": 8}, {"static_pct": 0}, {"static_pct": 90},
-                     {"refill_min": 1}, {"refill_min": 64}, {"split_shade": 0}, {"split_shade": 1}, {"pipes": 2},
+                     {"refill_min": 1}, {"refill_min": 64}, {"split_shade": 0}, {"split_shade": 1}, {"split_shade": 2}, {"pipes": 2},
                      {"pipes": 2, "sub_frames": 1}, {"rel_boxes": 0}, {"wide4": 0}, {"wide4": 0, "steal": 0},
                      {"wide4": 0, "rel_boxes": 0}, {"tail_stage": 2}, {"tail_stage": 3, "wide4": 0}, {"refill_min": 16}):
             s2 = bunny_small.upload(hip)
