@@ -66,6 +66,8 @@ struct DevScene {
   uint32_t root_ref;
   int32_t n_tri;
   const float4* hdr;   // RGBA texels, row 0 = top
+  const uint32_t* hdr_rgbe; // the same map as R | G << 8 | B << 16 | E << 24 when EVERY texel is exactly (m / 256) 2^(E - 128)
+                            // per channel -- true by construction for maps HDRLoader decoded (hdrloader.cpp:97-114) -- else NULL
   const float4* cache; // (x/w, y/h, pdf, 0)
   int32_t env_w, env_h, env_filter;
   uint32_t sobol_mask; // 7: Sobol dimensions wrap d & 7 (the reference's table), 15: sixteen dimensions (ezrt_scene_set_sampler)
@@ -399,6 +401,39 @@ EZD f3 tex_fetch(const float4* __restrict__ img, int W, int H, int filter, float
   return mix3(top, bot, fy);
 }
 
+// The environment map through its RGBE form when it has one (DevScene::hdr_rgbe): 4 bytes per texel instead of 16, so
+// a 1024x512 map is 2 MB and stays in every XCD's L2 (the float4 map is 8 MB and the bounce rays' lookups are random).
+// Decoding reproduces HDRLoader's convertComponent exactly: (m / 256) * 2^(E - 128) = ldexp(m, E - 136), exact in fp32
+// down to the subnormals.
+EZD f3 rgbe_texel(uint32_t p) {
+  const int e = (int)(p >> 24) - 136;
+  return mk(__builtin_amdgcn_ldexpf((float)(p & 255u), e), __builtin_amdgcn_ldexpf((float)((p >> 8) & 255u), e),
+            __builtin_amdgcn_ldexpf((float)((p >> 16) & 255u), e));
+}
+EZD f3 tex_fetch_rgbe(const uint32_t* __restrict__ img, int W, int H, int filter, float u, float v) {
+  u = sane01(u);
+  v = sane01(v);
+  if (filter == EZRT_FILTER_NEAREST) {
+    int ix = (int)ez_floor(u * (float)W), iy = (int)ez_floor(v * (float)H);
+    if (ix > W - 1) ix = W - 1;
+    if (iy > H - 1) iy = H - 1;
+    return rgbe_texel(img[(size_t)iy * W + ix]);
+  }
+  float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+  float x0 = ez_floor(x), y0 = ez_floor(y);
+  float fx = x - x0, fy = y - y0;
+  int ix0 = (int)x0, iy0 = (int)y0, ix1 = ix0 + 1, iy1 = iy0 + 1;
+  if (ix0 < 0) ix0 = 0;
+  if (iy0 < 0) iy0 = 0;
+  if (ix1 > W - 1) ix1 = W - 1;
+  if (iy1 > H - 1) iy1 = H - 1;
+  const uint32_t q00 = img[(size_t)iy0 * W + ix0], q10 = img[(size_t)iy0 * W + ix1];
+  const uint32_t q01 = img[(size_t)iy1 * W + ix0], q11 = img[(size_t)iy1 * W + ix1];
+  f3 top = mix3(rgbe_texel(q00), rgbe_texel(q10), fx);
+  f3 bot = mix3(rgbe_texel(q01), rgbe_texel(q11), fx);
+  return mix3(top, bot, fy);
+}
+
 // toSphericalCoord: P5/fsh:684-690
 EZD void to_spherical(f3 v, float& u, float& w) {
   u = ez_atan2(v.z, v.x);
@@ -416,7 +451,8 @@ EZD f3 hdr_color(const DevScene& sc, f3 L, float env_clamp, Counters& ctr) {
   if (!sc.hdr) return mk(0, 0, 0);
   float u, v;
   to_spherical(normalize(L), u, v);
-  f3 c = tex_fetch(sc.hdr, sc.env_w, sc.env_h, sc.env_filter, u, v);
+  f3 c = sc.hdr_rgbe ? tex_fetch_rgbe(sc.hdr_rgbe, sc.env_w, sc.env_h, sc.env_filter, u, v)
+                     : tex_fetch(sc.hdr, sc.env_w, sc.env_h, sc.env_filter, u, v);
   if (env_clamp > 0.0f) c = mk(ez_min(c.x, env_clamp), ez_min(c.y, env_clamp), ez_min(c.z, env_clamp));
   return c;
 }

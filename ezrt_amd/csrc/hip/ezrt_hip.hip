@@ -88,6 +88,7 @@ struct Tuning {
   int tail_stage = 0;      // from this stage on (>= 2; 0: never -- the default: measured 1.95 ms vs 0.43 ms for stages 2-4 of C2) the surviving paths finish in tail_kernel, one lane per
                            // path, instead of one trace + shading stage per bounce (ezrt_wavefront.h)
   int debug_stages = 0;    // print per-stage queue sizes (synchronises)
+  int env_rgbe = 1;        // environment lookups through the 4-byte RGBE form of the map when it has an exact one (set_env)
   int audit_via_queue = 0; // 1: ezrt_query_hits and ezrt_render_paths run through the TIMED kernels (traceq_kernel with
                            // the template, LDS layout, stealing and redo launch of a render call + the streaming shading
                            // stages) instead of the in-order audit kernels; 2 (query only): additionally treat the rays as
@@ -117,6 +118,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"wide4", &Tuning::wide4, 0, 1},
                               {"tail_stage", &Tuning::tail_stage, 0, 64},
                               {"debug_stages", &Tuning::debug_stages, 0, 2},
+                              {"env_rgbe", &Tuning::env_rgbe, 0, 1},
                               {"audit_via_queue", &Tuning::audit_via_queue, 0, 2}};
 Tuning tuning_from_env() {
   Tuning t;
@@ -166,6 +168,8 @@ struct EzrtScene {
   int stack_need4 = 1;        // LDS stack rows the 4-wide traversal can need (exact worst case over hit patterns)
   uint32_t root4 = 0;
   DevBuf<float4> hdr, cache;
+  DevBuf<uint32_t> hdr_rgbe; // RGBE form of hdr (has_rgbe)
+  bool has_rgbe = false;
   uint32_t root_ref = 0;
   int env_w = 0, env_h = 0, env_filter = 0;
   bool has_cache = false;
@@ -201,6 +205,7 @@ struct EzrtScene {
     d.root_ref = root_ref;
     d.n_tri = n_tri;
     d.hdr = hdr.p;
+    d.hdr_rgbe = (has_rgbe && tune.env_rgbe) ? hdr_rgbe.p : nullptr;
     d.cache = has_cache ? cache.p : nullptr;
     d.env_w = env_w;
     d.env_h = env_h;
@@ -1128,6 +1133,48 @@ int ezrt_scene_set_env(EzrtScene* s, const float* hdr, const float* cache, int w
   for (size_t i = 0; i < n; i++) tmp[i] = make_float4(hdr[i * 3], hdr[i * 3 + 1], hdr[i * 3 + 2], 0.0f);
   HIP_TRY(s->hdr.ensure(n));
   HIP_TRY(hipMemcpy(s->hdr.p, tmp.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+  // RGBE form: every texel exactly (m / 256) * 2^(E - 128) per channel with one shared E (what HDRLoader produces)
+  s->has_rgbe = false;
+  {
+    std::vector<uint32_t> packed(n);
+    bool ok = true;
+    for (size_t i = 0; i < n && ok; i++) {
+      const float c[3] = {hdr[i * 3], hdr[i * 3 + 1], hdr[i * 3 + 2]};
+      uint32_t bits[3];
+      memcpy(bits, c, sizeof bits);
+      if ((bits[0] | bits[1] | bits[2]) == 0u) { // +0 +0 +0
+        packed[i] = 0u;
+        continue;
+      }
+      float mx = c[0] > c[1] ? c[0] : c[1];
+      mx = mx > c[2] ? mx : c[2];
+      if (!(mx > 0.0f) || !(c[0] >= 0.0f) || !(c[1] >= 0.0f) || !(c[2] >= 0.0f) || mx > 3.0e38f) { // negative, NaN, inf, -0
+        ok = false;
+        break;
+      }
+      int k = 0;
+      (void)frexpf(mx, &k); // mx = f * 2^k, f in [0.5, 1)
+      const int E = k + 128;
+      if (E < 0 || E > 255) {
+        ok = false;
+        break;
+      }
+      uint32_t m[3];
+      for (int j = 0; j < 3 && ok; j++) {
+        if (bits[j] == 0x80000000u) ok = false; // -0 would decode as +0
+        const float q = ldexpf(c[j], 8 - k); // exact scaling
+        const uint32_t mi = (uint32_t)q;
+        if (!(q >= 0.0f && q < 256.0f) || (float)mi != q || ldexpf((float)mi, E - 136) != c[j]) ok = false;
+        m[j] = mi;
+      }
+      if (ok) packed[i] = m[0] | (m[1] << 8) | (m[2] << 16) | ((uint32_t)E << 24);
+    }
+    if (ok) {
+      HIP_TRY(s->hdr_rgbe.ensure(n));
+      HIP_TRY(hipMemcpy(s->hdr_rgbe.p, packed.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+      s->has_rgbe = true;
+    }
+  }
   s->has_cache = false;
   if (cache) {
     for (size_t i = 0; i < n; i++) tmp[i] = make_float4(cache[i * 3], cache[i * 3 + 1], cache[i * 3 + 2], 0.0f);

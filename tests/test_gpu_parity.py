@@ -398,3 +398,37 @@ def test_invariant_divisor_division_is_exact(hip, oracle):
         got = hip.debug_math(17, n.view(np.float32), b.view(np.float32), n=n.size).view(np.uint32)
         assert np.array_equal(got, n // np.uint32(d)), d
         assert np.array_equal(oracle.debug_math(17, n.view(np.float32), b.view(np.float32), n=n.size).view(np.uint32), got)
+
+
+@pytest.mark.gpu
+def test_rgbe_form_of_the_env_map_is_exact(hip, oracle):
+    """A map HDRLoader decoded is (m / 256) 2^(E - 128) per channel: the trace then reads it as 4-byte RGBE texels (2 MB
+    instead of 8 for 1024x512).  Same images as the float4 path and as the oracle, bilinear and nearest, including a
+    map with tiny exponents (subnormal texels), a black texel and unnormalised mantissas; a map that is not RGBE-exact
+    silently keeps the float4 path."""
+    rng = np.random.default_rng(21)
+    rgbe = rng.integers(0, 256, (64, 128, 4), dtype=np.uint8)
+    rgbe[..., 3] = rng.integers(118, 140, (64, 128))
+    rgbe[0, :8, 3] = np.arange(8)               # E = 0..7: (m / 256) 2^-128 ... subnormal floats
+    rgbe[1, :4, :3] = 0                         # black with an arbitrary exponent
+    rgbe[2, :16, :3] = rng.integers(0, 16, (16, 3))   # unnormalised: largest mantissa < 128
+    env = ((rgbe[..., :3].astype(np.float32) / np.float32(256.0)) *
+           np.ldexp(np.float32(1.0), rgbe[..., 3].astype(np.int32) - 128)[..., None]).astype(np.float32)
+    shipped = scenes.shipped_hdr()
+    eye, cam = S.camera(30, 20, 4)
+    for name, hdr in (("random rgbe", env), ("shipped", shipped), ("not rgbe", (env * np.float32(1.0000001) + np.float32(1e-3)).astype(np.float32))):
+        bs = scenes.bunny_scene(subdiv=0, hdr=np.ascontiguousarray(hdr), want_cache=True)
+        for filt in (1, 0):
+            sg, so = bs.upload(hip), bs.upload(oracle)
+            sg.set_env(bs.hdr, bs.cache, filt)
+            so.set_env(bs.hdr, bs.cache, filt)
+            for integ in (50, 51):
+                p = trace.make_params(96, 64, eye, cam, integ, 3, spp=2)
+                want = so.render(p)
+                assert np.array_equal(_bits(sg.render(p)), _bits(want)), (name, filt, integ)
+                sg.set_option("env_rgbe", 0)
+                assert np.array_equal(_bits(sg.render(p)), _bits(want)), (name, filt, integ, "float4 path")
+                sg.set_option("env_rgbe", 1)
+                sg.set_option("megakernel", 1)
+                assert np.array_equal(_bits(sg.render(p)), _bits(want)), (name, filt, integ, "megakernel")
+                sg.set_option("megakernel", 0)
