@@ -23,7 +23,6 @@
 
 namespace ezd {
 
-constexpr uint32_t HIT_NOT_OWNED = 0xfffffffcu; // hit record (tri) of a queue-0 slot whose pixel this shard does not own
 constexpr uint32_t FLAG_SHADOW_SHOT = 1u;  // slot 2i holds a live env shadow ray
 constexpr uint32_t FLAG_TERMINATE = 2u;    // NdotL <= 0 (P5/fsh:854): finish after the shadow result
 constexpr uint32_t FLAG_PDF_DEAD = 4u;     // pdf_brdf <= 0 (P5/fsh:865): ray shot, then break
@@ -109,9 +108,8 @@ __global__ __launch_bounds__(BLOCK) void raygen_kernel(WfArgs a) {
   uint32_t frame;
   slot_to_pixel(a.blocks, a.div_blocks, queue_to_sample(slot, a.div_sub, a.scatter, a.scatter_shift), a.frame_first, x, y, frame);
   const EzrtRenderParams& p = a.p;
-  if (!pixel_owned(p, x, y)) { // no ray: the trace skips the slot, so its hit record keeps this marker for the shading stage
+  if (!pixel_owned(p, x, y)) {
     a.rq_out.d[slot] = make_float4(0, 0, 0, 0.0f);
-    a.hits_out[slot] = (unsigned long long)HIT_NOT_OWNED;
     return;
   }
   const uint32_t ix = (uint32_t)x, iy = (uint32_t)y;
@@ -220,17 +218,8 @@ EZD void shade_load(const WfArgs& a, const uint32_t i, const bool live, ShadeIn&
   // round trip) instead of discovering them one branch at a time
   const uint32_t ii = live ? i : 0u;
   const uint32_t rslot = (b == 0 || !MIS) ? ii : (2u * ii + 1u);
+  float4 rd4 = a.rq_in.d[rslot];
   int2 h = a.hits[rslot];
-  float4 rd4;
-  if (B0 && PASS == 1) {
-    // the primary stage's first pass only needs the direction of rays that LEFT the scene (environment lookup): a
-    // hit is listed for the second pass by its record alone, a slot without a ray carries raygen's marker -- 46 % of
-    // the directions (C2) are not read at all by this HBM-bound kernel
-    rd4 = make_float4(0.0f, 0.0f, 0.0f, (uint32_t)h.x == HIT_NOT_OWNED ? 0.0f : 1.0f);
-    if (h.x < 0 && (uint32_t)h.x != HIT_NOT_OWNED) rd4 = a.rq_in.d[rslot];
-  } else {
-    rd4 = a.rq_in.d[rslot];
-  }
   float4 ro4 = make_float4(p.eye[0], p.eye[1], p.eye[2], 0.0f);
   float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, s3 = s0, s4 = s0;
   int2 sh = make_int2(-1, 0);
