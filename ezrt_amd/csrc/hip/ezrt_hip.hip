@@ -88,6 +88,10 @@ struct Tuning {
   int tail_stage = 0;      // from this stage on (>= 2; 0: never -- the default: measured 1.95 ms vs 0.43 ms for stages 2-4 of C2) the surviving paths finish in tail_kernel, one lane per
                            // path, instead of one trace + shading stage per bounce (ezrt_wavefront.h)
   int debug_stages = 0;    // print per-stage queue sizes (synchronises)
+  int redo_overlap = 1;    // the redo launch of a stage (exact ties, rays that are not tame: a handful of rays, but ~50 us of
+                           // dependent traversal steps) runs on a side stream under the stage's first shading pass; the
+                           // second pass waits for it (0: in line, before any shading)
+  int debug_force_pending = 0; // test hook: every k-th ray slot takes the not-tame route (HIT_PENDING -> redo -> second pass)
   int env_rgbe = 1;        // environment lookups through the 4-byte RGBE form of the map when it has an exact one (set_env)
   int audit_via_queue = 0; // 1: ezrt_query_hits and ezrt_render_paths run through the TIMED kernels (traceq_kernel with
                            // the template, LDS layout, stealing and redo launch of a render call + the streaming shading
@@ -119,6 +123,8 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"tail_stage", &Tuning::tail_stage, 0, 64},
                               {"debug_stages", &Tuning::debug_stages, 0, 2},
                               {"env_rgbe", &Tuning::env_rgbe, 0, 1},
+                              {"redo_overlap", &Tuning::redo_overlap, 0, 1},
+                              {"debug_force_pending", &Tuning::debug_force_pending, 0, 1 << 20},
                               {"audit_via_queue", &Tuning::audit_via_queue, 0, 2}};
 Tuning tuning_from_env() {
   Tuning t;
@@ -153,6 +159,9 @@ struct Pipe {
   DevBuf<float4> inner4_rel;    // 4-wide records translated by -eye
   DevBuf<uint32_t> defer_list;  // split shading: paths with a surface interaction, per workgroup
   DevBuf<uint32_t> defer_count;
+  hipStream_t side = nullptr;    // redo launches that overlap the first shading pass
+  hipEvent_t ev_main = nullptr;  // a stage's main trace launch is enqueued / done
+  hipEvent_t ev_redo = nullptr;  // ... its redo launch is done
   hipStream_t stream = nullptr;  // own stream (pipelined calls only)
   hipEvent_t ev_done = nullptr;  // samples of the sub-chunk are complete
   hipEvent_t ev_free = nullptr;  // ... and have been folded into the frame buffer
@@ -309,6 +318,9 @@ int ensure_events(EzrtScene* s) {
   }
   for (Pipe& q : s->pipe) {
     HIP_TRY(hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&q.side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&q.ev_main, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&q.ev_redo, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&q.ev_done, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&q.ev_free, hipEventDisableTiming));
   }
@@ -449,29 +461,28 @@ void launch_shade_i(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
   else if (a.bounce == 1) launch_shade_is<INTEG, 1>(a, full, grid, st);
   else launch_shade_is<INTEG, 2>(a, full, grid, st);
 }
+// `between` (or NULL): an event the second pass waits for -- the stage's redo launch on the side stream
 template <int INTEG, int STAGE>
-void launch_shade_split_ib(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st) {
-  if (full) {
-    hipLaunchKernelGGL((shade_miss_kernel<INTEG, true, STAGE>), grid, dim3(SHADE_BLOCK), 0, st, a);
-    hipLaunchKernelGGL((shade_hit_kernel<INTEG, true, STAGE>), grid_hit, dim3(SHADE_BLOCK), 0, st, a);
-  } else {
-    hipLaunchKernelGGL((shade_miss_kernel<INTEG, false, STAGE>), grid, dim3(SHADE_BLOCK), 0, st, a);
-    hipLaunchKernelGGL((shade_hit_kernel<INTEG, false, STAGE>), grid_hit, dim3(SHADE_BLOCK), 0, st, a);
-  }
+void launch_shade_split_ib(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st, hipEvent_t between) {
+  if (full) hipLaunchKernelGGL((shade_miss_kernel<INTEG, true, STAGE>), grid, dim3(SHADE_BLOCK), 0, st, a);
+  else hipLaunchKernelGGL((shade_miss_kernel<INTEG, false, STAGE>), grid, dim3(SHADE_BLOCK), 0, st, a);
+  if (between) (void)hipStreamWaitEvent(st, between, 0);
+  if (full) hipLaunchKernelGGL((shade_hit_kernel<INTEG, true, STAGE>), grid_hit, dim3(SHADE_BLOCK), 0, st, a);
+  else hipLaunchKernelGGL((shade_hit_kernel<INTEG, false, STAGE>), grid_hit, dim3(SHADE_BLOCK), 0, st, a);
 }
 template <int INTEG>
-void launch_shade_split_i(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st) {
-  if (a.bounce == 0) launch_shade_split_ib<INTEG, 0>(a, full, grid, grid_hit, st);
-  else if (a.bounce == 1) launch_shade_split_ib<INTEG, 1>(a, full, grid, grid_hit, st);
-  else launch_shade_split_ib<INTEG, 2>(a, full, grid, grid_hit, st);
+void launch_shade_split_i(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st, hipEvent_t between) {
+  if (a.bounce == 0) launch_shade_split_ib<INTEG, 0>(a, full, grid, grid_hit, st, between);
+  else if (a.bounce == 1) launch_shade_split_ib<INTEG, 1>(a, full, grid, grid_hit, st, between);
+  else launch_shade_split_ib<INTEG, 2>(a, full, grid, grid_hit, st, between);
 }
-void launch_shade_split(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st) {
+void launch_shade_split(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st, hipEvent_t between) {
   switch (a.p.integrator) {
-    case EZRT_INTEGRATOR_P3_DIFFUSE: launch_shade_split_i<EZRT_INTEGRATOR_P3_DIFFUSE>(a, full, grid, grid_hit, st); break;
-    case EZRT_INTEGRATOR_P4_DISNEY: launch_shade_split_i<EZRT_INTEGRATOR_P4_DISNEY>(a, full, grid, grid_hit, st); break;
-    case EZRT_INTEGRATOR_P5_SOBOL: launch_shade_split_i<EZRT_INTEGRATOR_P5_SOBOL>(a, full, grid, grid_hit, st); break;
-    case EZRT_INTEGRATOR_P5_MIS_ANISO: launch_shade_split_i<EZRT_INTEGRATOR_P5_MIS_ANISO>(a, full, grid, grid_hit, st); break;
-    default: launch_shade_split_i<EZRT_INTEGRATOR_P5_MIS>(a, full, grid, grid_hit, st); break;
+    case EZRT_INTEGRATOR_P3_DIFFUSE: launch_shade_split_i<EZRT_INTEGRATOR_P3_DIFFUSE>(a, full, grid, grid_hit, st, between); break;
+    case EZRT_INTEGRATOR_P4_DISNEY: launch_shade_split_i<EZRT_INTEGRATOR_P4_DISNEY>(a, full, grid, grid_hit, st, between); break;
+    case EZRT_INTEGRATOR_P5_SOBOL: launch_shade_split_i<EZRT_INTEGRATOR_P5_SOBOL>(a, full, grid, grid_hit, st, between); break;
+    case EZRT_INTEGRATOR_P5_MIS_ANISO: launch_shade_split_i<EZRT_INTEGRATOR_P5_MIS_ANISO>(a, full, grid, grid_hit, st, between); break;
+    default: launch_shade_split_i<EZRT_INTEGRATOR_P5_MIS>(a, full, grid, grid_hit, st, between); break;
   }
 }
 void launch_shade(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
@@ -642,6 +653,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     t.redo_count = pp.qcounts.p + 128 + b;
     t.redo_slots = pp.redo_slots.p;
     t.redo_flag = pp.redo_flag.p;
+    t.force_pending = (uint32_t)tu.debug_force_pending;
     t.wave_log = nullptr;
     if (debug_stages >= 2) {
       HIP_TRY(pp.wave_log.ensure((size_t)trace_grid_full * (BLOCK / 64) * 8));
@@ -649,6 +661,11 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
       t.wave_log = pp.wave_log.p;
     }
     auto launch_traceq = [&](const TraceQArgs& q, bool small = false) { launch_traceq_cfg(s, cfg, q, small, st); };
+    const bool split_here = tu.split_shade == 3 ? b <= 1 : ((b >= 1 && tu.split_shade) || tu.split_shade >= 2);
+    // the redo launch under the first shading pass: only where the first pass cannot be misled by a record the redo
+    // launch is still to write -- traceq4_kernel marks those HIT_PENDING -- and only in plain timed runs
+    const bool overlap_redo = wide && split_here && tu.redo_overlap && !full && !plog && !debug_stages && !(b == 0 && use_packet);
+    hipEvent_t ev_between = nullptr;
     int e = s->n_trace_events;
     if (e < MAX_TRACE_EVENTS) HIP_TRY(hipEventRecord(s->ev_trace[e][0], st));
     if (b == 0 && !full && use_packet) {
@@ -695,7 +712,16 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
         r.head = pp.qheads.p + (size_t)(40 + b) * HEAD_SLOT;
         r.dbg = nullptr;
         r.wave_log = nullptr;
-        launch_traceq(r, true);
+        r.force_pending = 0u;
+        if (overlap_redo) {
+          HIP_TRY(hipEventRecord(pp.ev_main, st));
+          HIP_TRY(hipStreamWaitEvent(pp.side, pp.ev_main, 0));
+          launch_traceq_cfg(s, cfg, r, true, pp.side);
+          HIP_TRY(hipEventRecord(pp.ev_redo, pp.side));
+          ev_between = pp.ev_redo;
+        } else {
+          launch_traceq(r, true);
+        }
       }
     }
     if (e < MAX_TRACE_EVENTS) {
@@ -740,8 +766,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     a.bounce = b;
     a.defer_list = pp.defer_list.p;
     a.defer_count = pp.defer_count.p;
-    if (tu.split_shade == 3 ? b <= 1 : ((b >= 1 && tu.split_shade) || tu.split_shade >= 2))
-      launch_shade_split(a, full, dim3(shade_grid), dim3(shade_grid), st);
+    if (split_here) launch_shade_split(a, full, dim3(shade_grid), dim3(shade_grid), st, ev_between);
     else launch_shade(a, full, dim3(shade_grid), st);
     if (debug_stages) { // diagnostic only: per-stage queue sizes and counters (synchronises)
       uint32_t q[2] = {0, 0};
@@ -1113,6 +1138,9 @@ void ezrt_scene_destroy(EzrtScene* s) {
     (void)hipEventDestroy(s->ev_end);
     for (Pipe& q : s->pipe) {
       if (q.stream) (void)hipStreamDestroy(q.stream);
+      if (q.side) (void)hipStreamDestroy(q.side);
+      if (q.ev_main) (void)hipEventDestroy(q.ev_main);
+      if (q.ev_redo) (void)hipEventDestroy(q.ev_redo);
       if (q.ev_done) (void)hipEventDestroy(q.ev_done);
       if (q.ev_free) (void)hipEventDestroy(q.ev_free);
     }
@@ -1442,6 +1470,7 @@ int ezrt_query_hits(EzrtScene* s, const float* rays, int n_rays, int32_t* tri_id
     t.redo_count = pp.qcounts.p + 128;
     t.redo_slots = pp.redo_slots.p;
     t.redo_flag = pp.redo_flag.p;
+    t.force_pending = 0u;
     t.wave_log = nullptr;
     if (wide) launch_traceq4_cfg(s, trace_cfg4(s), t, rel4, nullptr);
     else launch_traceq_cfg(s, cfg, t, false, nullptr);

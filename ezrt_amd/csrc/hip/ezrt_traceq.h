@@ -69,9 +69,17 @@ struct TraceQArgs {
   uint32_t* redo_count;
   uint32_t* redo_slots;
   uint32_t* redo_flag; // one word per ray slot: a ray is appended once (cleared again by the redo launch)
+  uint32_t force_pending;       // test hook (knob debug_force_pending = k > 0): traceq4_kernel treats every ray whose slot is a
+                                // multiple of k as not tame, i.e. sends it through the pending -> redo -> second-pass route
   unsigned long long* wave_log; // diagnostic (debug_stages=2): per wave 8 words {start, end (100 MHz ticks), iterations |
                                 // inner steps, rays | inner lanes, leaf rays | leaf rounds, busy lanes, -, -}
 };
+
+// Hit record (tri) of a ray traceq4_kernel handed to the redo list WITHOUT an answer (a ray that is not tame): the
+// shading stage's first pass, which runs while the redo launch is still tracing, defers such a path to its second
+// pass instead of reading it as a miss.  (A ray on the redo list because of an exact tie already has a hit record --
+// one of the tied triangles -- and "hit" is all the first pass needs to know.)
+constexpr int32_t HIT_PENDING = -5;
 
 EZD uint32_t lane_rank(unsigned long long mask) { // number of set bits below this lane
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));

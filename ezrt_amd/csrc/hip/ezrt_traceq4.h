@@ -180,9 +180,10 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
           sp = 0;
           sb = 0;
           // a ray that is not tame (NaNs possible in the slab test, monotonicity lost) is not this kernel's: it is
-          // "finished" at once with the tie flag set, i.e. published as a miss and appended to the redo list
-          tie = !ray_is_tame(S, inv);
+          // "finished" at once with the tie flag set, i.e. published as PENDING and appended to the redo list
+          tie = !ray_is_tame(S, inv) || (a.force_pending && adopted % a.force_pending == 0u);
           ref = tie ? REF_DONE : A.root4;
+          best_tri = tie ? HIT_PENDING : -1;
         }
       }
       const bool need = nx_slot == REF_NONE && !exhausted;

@@ -298,6 +298,7 @@ EZD bool shade_body(const WfArgs& a, const uint32_t i, bool live, const ShadeIn&
       live = false; // pixel not owned by this shard
     } else {
       if (PASS != 2) n_samples = n_samples + 1;
+      if (PASS == 1 && h.x == HIT_PENDING) return true; // answer still with the redo launch: decided in the second pass
       if (h.x < 0) { // primary miss: P5/fsh:931-933
         colour = hdr_color<FULLCTR>(sc, rd, p.env_clamp, ctr);
         done = true;
@@ -320,6 +321,9 @@ EZD bool shade_body(const WfArgs& a, const uint32_t i, bool live, const ShadeIn&
       }
     }
   } else {
+    // a slot the previous stage's second pass left empty (a path that was pending there and then left the scene): it
+    // holds no ray (w = 0), no hit record and no state -- nothing below may be read
+    if (!MIS && rd4.w == 0.0f) return false;
     if (COMPACT) {
       cosine = s0.w;
       pdf = 1.0f / (2.0f * PI); // (what the bounce wrote: P5/fsh:774)
@@ -350,6 +354,7 @@ EZD bool shade_body(const WfArgs& a, const uint32_t i, bool live, const ShadeIn&
       Le0 = mk(s3.x, s3.y, s3.z);
       seed = __float_as_uint(s3.w);
     }
+    if (PASS == 1 && (h.x == HIT_PENDING || (MIS && sh.x == HIT_PENDING))) return true; // (see HIT_PENDING)
     if (MIS) {
       flags = __float_as_uint(s4.w);
       if (flags & FLAG_SHADOW_SHOT) { // P5/fsh:826-841
@@ -597,6 +602,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_hit_kernel(WfArgs a) {
       ShadeOut o;
       shade_path<INTEG, FULLCTR, 2, STAGE>(a, list[j], true, ctr, n_samples, o);
       if (o.emit) shade_store<MIS, FORM>(a, o, base + j);
+      else if (a.bounce < a.p.max_bounce) // (a path that was pending and turned out to leave the scene: no ray in its slot)
+        a.rq_out.d[base + j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
   } else {
     for (uint32_t j0 = 0; j0 < cnt; j0 += SHADE_BLOCK) { // (workgroup-uniform trip count: barriers inside)

@@ -264,7 +264,10 @@ def test_schedule_knobs_never_change_results(hip, bunny_small):
                      {"scatter": 0}, {"scatter": 5}, {"scatter": 8}, {"static_pct": 0}, {"static_pct": 90},
                      {"refill_min": 1}, {"refill_min": 64}, {"split_shade": 0}, {"split_shade": 1}, {"split_shade": 2}, {"pipes": 2},
                      {"pipes": 2, "sub_frames": 1}, {"rel_boxes": 0}, {"wide4": 0}, {"wide4": 0, "steal": 0},
-                     {"wide4": 0, "rel_boxes": 0}, {"tail_stage": 2}, {"tail_stage": 3, "wide4": 0}, {"refill_min": 16}):
+                     {"wide4": 0, "rel_boxes": 0}, {"tail_stage": 2}, {"tail_stage": 3, "wide4": 0}, {"refill_min": 16},
+                     {"redo_overlap": 0}, {"env_rgbe": 0}, {"debug_force_pending": 3}, {"debug_force_pending": 1},
+                     {"debug_force_pending": 5, "redo_overlap": 0}, {"debug_force_pending": 2, "split_shade": 2},
+                     {"debug_force_pending": 7, "split_shade": 1}, {"debug_force_pending": 4, "split_shade": 0}):
             s2 = bunny_small.upload(hip)
             for k, v in opts.items():
                 s2.set_option(k, v)
@@ -432,3 +435,33 @@ def test_rgbe_form_of_the_env_map_is_exact(hip, oracle):
                 sg.set_option("megakernel", 1)
                 assert np.array_equal(_bits(sg.render(p)), _bits(want)), (name, filt, integ, "megakernel")
                 sg.set_option("megakernel", 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("integ", [3, 4, 50, 51, 52])
+def test_pending_rays_take_the_redo_route_under_the_first_shading_pass(hip, oracle, bunny_small, integ):
+    """Rays traceq4_kernel hands to the redo list without an answer (not tame) are published as HIT_PENDING; the redo
+    launch runs on a side stream under the stage's first shading pass, which defers such paths to the second pass --
+    where they may turn out to be hits OR misses (a miss leaves an empty slot in the next queue).  The test hook sends
+    every k-th ray slot that way: images, path logs and ray counts must not change."""
+    sg, so = bunny_small.upload(hip), bunny_small.upload(oracle)
+    eye, cam = S.camera(25, 10, 4)
+    p = trace.make_params(128, 96, eye, cam, integ, 3, spp=3, rect=(5, 3, 120, 90))
+    want = so.render(p)
+    to, do, co = so.render_paths(p)
+    rays = so.counters()["rays"]
+    for k in (1, 2, 3, 11):
+        sg.set_option("debug_force_pending", k)
+        sg.counters_reset()
+        assert np.array_equal(_bits(sg.render(p)), _bits(want)), (integ, k)
+        sg.set_option("audit_via_queue", 1)
+        tg, dg, cg = sg.render_paths(p)
+        sg.set_option("audit_via_queue", 0)
+        assert np.array_equal(tg, to) and np.array_equal(_bits(dg), _bits(do)) and np.array_equal(_bits(cg), _bits(co)), (integ, k)
+    assert rays > 0
+    sg.set_option("debug_force_pending", 2)
+    sg.counters_reset()
+    so.counters_reset()
+    sg.render(p)
+    so.render(p)
+    assert sg.counters()["rays"] == so.counters()["rays"] and sg.counters()["samples"] == so.counters()["samples"]
