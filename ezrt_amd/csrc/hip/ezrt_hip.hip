@@ -385,11 +385,13 @@ void launch_traceq_cfg(EzrtScene* s, const TraceCfg& c, const TraceQArgs& q, boo
   s->n_trace_launches++;
 }
 // the same for traceq4_kernel: fewer stack rows (stack_need4), 112-B records in LDS
-TraceCfg trace_cfg4(const EzrtScene* s) {
+// rel: the launch traverses boxes translated by a common origin (traceq4_kernel<.., true>); the other variant keeps
+// the ray directions in LDS (3 floats per lane after the lane table)
+TraceCfg trace_cfg4(const EzrtScene* s, bool rel) {
   TraceCfg c;
   const Tuning& tu = s->tune;
   c.lds = (size_t)s->stack_need4 * BLOCK * sizeof(int);
-  const size_t lds_fixed = c.lds + BLOCK * sizeof(int);
+  const size_t lds_fixed = c.lds + BLOCK * sizeof(int) + (rel ? 0 : 3 * BLOCK * sizeof(float));
   int blocks_per_cu = tu.trace_wps > 0 ? tu.trace_wps : 5;
   if ((size_t)blocks_per_cu * lds_fixed > 158 * 1024) blocks_per_cu = (int)((158 * 1024) / lds_fixed);
   if (blocks_per_cu < 1) blocks_per_cu = 1;
@@ -409,7 +411,7 @@ TraceCfg trace_cfg4(const EzrtScene* s) {
 // whether the timed stages of this scene run traceq4_kernel
 bool use_wide4(const EzrtScene* s) {
   return s->tune.wide4 && s->n_inner4 > 0 && s->instr == 0 &&
-         ((size_t)s->stack_need4 + 1) * BLOCK * sizeof(int) <= 60 * 1024;
+         ((size_t)s->stack_need4 + 4) * BLOCK * sizeof(int) <= 60 * 1024; // stack rows + lane table + direction columns
 }
 template <bool REL>
 void launch_traceq4_rel(EzrtScene* s, const TraceCfg& c, const TraceQ4Args& q, hipStream_t st) {
@@ -596,7 +598,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     hipLaunchKernelGGL(inner_rel_kernel, dim3((unsigned)((s->n_inner + 255) / 256)), dim3(256), 0, st, s->inner.p, s->n_inner,
                        p->eye[0], p->eye[1], p->eye[2], pp.inner_rel.p);
   }
-  const TraceCfg cfg4 = wide ? trace_cfg4(s) : TraceCfg();
+  const TraceCfg cfg4_rel = wide ? trace_cfg4(s, true) : TraceCfg(), cfg4_abs = wide ? trace_cfg4(s, false) : TraceCfg();
   if (wide && s->tune.rel_boxes) {
     HIP_TRY(pp.inner4_rel.ensure((size_t)s->n_inner4 * N4_FLOAT4));
     hipLaunchKernelGGL(inner4_rel_kernel, dim3((unsigned)((s->n_inner4 + 255) / 256)), dim3(256), 0, st, s->inner4.p, s->n_inner4,
@@ -700,7 +702,10 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
       t.redo_flag = nullptr;
       launch_traceq(t);
     } else {
-      if (wide) launch_traceq4_cfg(s, cfg4, t, (b == 0 && tu.rel_boxes) ? pp.inner4_rel.p : nullptr, st);
+      if (wide) {
+        const bool rel = b == 0 && tu.rel_boxes;
+        launch_traceq4_cfg(s, rel ? cfg4_rel : cfg4_abs, t, rel ? pp.inner4_rel.p : nullptr, st);
+      }
       else launch_traceq(t);
       if (t.steal || wide) { // rays that met an exact distance tie, or (4-wide) are not tame -- normally none: reference order, plain stores
         TraceQArgs r = t;
@@ -1472,7 +1477,7 @@ int ezrt_query_hits(EzrtScene* s, const float* rays, int n_rays, int32_t* tri_id
     t.redo_flag = pp.redo_flag.p;
     t.force_pending = 0u;
     t.wave_log = nullptr;
-    if (wide) launch_traceq4_cfg(s, trace_cfg4(s), t, rel4, nullptr);
+    if (wide) launch_traceq4_cfg(s, trace_cfg4(s, rel4 != nullptr), t, rel4, nullptr);
     else launch_traceq_cfg(s, cfg, t, false, nullptr);
     if (t.steal || wide) {
       TraceQArgs r = t;
