@@ -66,6 +66,9 @@ struct Tuning {
   int leaf_threshold = 24; // lanes waiting at a leaf that trigger the triangle phase
   int pool_div = 1;        // ray-index pool = clamp(n_rays / (n_waves * pool_div), 8, pool_max)
   int pool_max = 128;      // rays per dynamic reservation (two 8x8 sub-blocks; affordable since the reservations spread over 8 counters)
+  int dir_lds = 1;         // bounce stages: ray directions in LDS columns instead of VGPRs where the LDS has room (8 -> 5 spilled registers)
+  int trace_wps_rel = 7;   // waves per SIMD of the primary stage's launch (traceq4_kernel<.., true>; 0: trace_wps).  That variant
+                           // needs 79 VGPRs; at 72 it spills 7 and is still 1.5 % faster (seven waves hide more latency)
   int trace_wps = 6;       // traceq_kernel register budget: waves per SIMD (4, 5, 6 or 8); 6 = 80 VGPRs (8 B of
                            // scratch) and fewer tree records in LDS, still +3.6 % over 5 since the loop got leaner
   int lds_nodes = 1 << 20; // cap on top-of-tree records staged in LDS
@@ -110,6 +113,8 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"pool_div", &Tuning::pool_div, 1, 1 << 16},
                               {"pool_max", &Tuning::pool_max, 8, 4096},
                               {"trace_wps", &Tuning::trace_wps, 1, 8},
+                              {"trace_wps_rel", &Tuning::trace_wps_rel, 0, 8},
+                              {"dir_lds", &Tuning::dir_lds, 0, 1},
                               {"lds_nodes", &Tuning::lds_nodes, 0, 1 << 24},
                               {"steal", &Tuning::steal, 0, 1},
                               {"rel_boxes", &Tuning::rel_boxes, 0, 1},
@@ -387,11 +392,31 @@ void launch_traceq_cfg(EzrtScene* s, const TraceCfg& c, const TraceQArgs& q, boo
 // the same for traceq4_kernel: fewer stack rows (stack_need4), 112-B records in LDS
 // rel: the launch traverses boxes translated by a common origin (traceq4_kernel<.., true>); the other variant keeps
 // the ray directions in LDS (3 floats per lane after the lane table)
+// waves per SIMD of a traceq4 launch: the primary stage's variant may run one more (trace_wps_rel), but only while
+// that still leaves room for a useful top of the tree in LDS (deep trees need the space for stack rows: C5 and C3
+// would stage ONE record at 7 workgroups per CU and lose 3 %)
+int records_staged4(const EzrtScene* s, bool dir_in_lds, int wps) {
+  const size_t lds_fixed = (size_t)s->stack_need4 * BLOCK * sizeof(int) + BLOCK * sizeof(int) + (dir_in_lds ? 3 * BLOCK * sizeof(float) : 0);
+  size_t budget = (size_t)(158 * 1024) / (size_t)(wps > 0 ? wps : 1);
+  if (budget > 64 * 1024) budget = 64 * 1024;
+  budget -= budget / 16;
+  return budget > lds_fixed ? (int)((budget - lds_fixed) / (N4_LDS_DWORDS * 4)) : 0;
+}
+int wps4(const EzrtScene* s, bool rel) {
+  const int w = s->tune.trace_wps_rel;
+  if (rel && w > 0 && (w <= s->tune.trace_wps || records_staged4(s, false, w) >= std::min(24, s->n_inner4))) return w;
+  return s->tune.trace_wps;
+}
+// the bounce stages' variant with the ray directions in LDS: 3 KB per workgroup that deep trees need for stack rows
+bool dir_in_lds4(const EzrtScene* s, bool rel) {
+  return !rel && s->tune.dir_lds && records_staged4(s, true, s->tune.trace_wps) >= std::min(24, s->n_inner4);
+}
 TraceCfg trace_cfg4(const EzrtScene* s, bool rel) {
   TraceCfg c;
-  const Tuning& tu = s->tune;
+  Tuning tu = s->tune;
+  tu.trace_wps = wps4(s, rel);
   c.lds = (size_t)s->stack_need4 * BLOCK * sizeof(int);
-  const size_t lds_fixed = c.lds + BLOCK * sizeof(int) + (rel ? 0 : 3 * BLOCK * sizeof(float));
+  const size_t lds_fixed = c.lds + BLOCK * sizeof(int) + (dir_in_lds4(s, rel) ? 3 * BLOCK * sizeof(float) : 0);
   int blocks_per_cu = tu.trace_wps > 0 ? tu.trace_wps : 5;
   if ((size_t)blocks_per_cu * lds_fixed > 158 * 1024) blocks_per_cu = (int)((158 * 1024) / lds_fixed);
   if (blocks_per_cu < 1) blocks_per_cu = 1;
@@ -411,16 +436,17 @@ TraceCfg trace_cfg4(const EzrtScene* s, bool rel) {
 // whether the timed stages of this scene run traceq4_kernel
 bool use_wide4(const EzrtScene* s) {
   return s->tune.wide4 && s->n_inner4 > 0 && s->instr == 0 &&
-         ((size_t)s->stack_need4 + 4) * BLOCK * sizeof(int) <= 60 * 1024; // stack rows + lane table + direction columns
+         ((size_t)s->stack_need4 + 1) * BLOCK * sizeof(int) <= 60 * 1024; // stack rows + lane table
 }
-template <bool REL>
+template <bool REL, bool DLDS>
 void launch_traceq4_rel(EzrtScene* s, const TraceCfg& c, const TraceQ4Args& q, hipStream_t st) {
-  const int trace_wps = s->tune.trace_wps;
+  const int trace_wps = wps4(s, REL);
   const dim3 grid(c.grid_full), block(BLOCK);
-  if (trace_wps == 8) hipLaunchKernelGGL((traceq4_kernel<8, REL>), grid, block, c.lds_t, st, q);
-  else if (trace_wps == 6) hipLaunchKernelGGL((traceq4_kernel<6, REL>), grid, block, c.lds_t, st, q);
-  else if (trace_wps == 4) hipLaunchKernelGGL((traceq4_kernel<4, REL>), grid, block, c.lds_t, st, q);
-  else hipLaunchKernelGGL((traceq4_kernel<5, REL>), grid, block, c.lds_t, st, q);
+  if (trace_wps == 8) hipLaunchKernelGGL((traceq4_kernel<8, REL, DLDS>), grid, block, c.lds_t, st, q);
+  else if (trace_wps == 7) hipLaunchKernelGGL((traceq4_kernel<7, REL, DLDS>), grid, block, c.lds_t, st, q);
+  else if (trace_wps == 6) hipLaunchKernelGGL((traceq4_kernel<6, REL, DLDS>), grid, block, c.lds_t, st, q);
+  else if (trace_wps == 4) hipLaunchKernelGGL((traceq4_kernel<4, REL, DLDS>), grid, block, c.lds_t, st, q);
+  else hipLaunchKernelGGL((traceq4_kernel<5, REL, DLDS>), grid, block, c.lds_t, st, q);
   s->n_trace_launches++;
 }
 // t: the stage's queue arguments as for the binary kernel (knobs already filled); rel: 4-wide records translated by
@@ -435,8 +461,9 @@ void launch_traceq4_cfg(EzrtScene* s, const TraceCfg& c4, const TraceQArgs& t, c
   A.inner4_rel = rel;
   A.root4 = s->root4;
   A.lds_nodes4 = c4.lds_nodes;
-  if (rel) launch_traceq4_rel<true>(s, c4, A, st);
-  else launch_traceq4_rel<false>(s, c4, A, st);
+  if (rel) launch_traceq4_rel<true, false>(s, c4, A, st);
+  else if (dir_in_lds4(s, false)) launch_traceq4_rel<false, true>(s, c4, A, st);
+  else launch_traceq4_rel<false, false>(s, c4, A, st);
 }
 
 // schedule fields of a traceq launch that come from the knobs (clamped: ADVICE r1)
@@ -605,6 +632,10 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
                        p->eye[0], p->eye[1], p->eye[2], pp.inner4_rel.p);
   }
   hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((n_slots + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, a);
+  if (s->tune.debug_stages && wide)
+    fprintf(stderr, "[ezrt] traceq4 launches: %d stack rows (binary tree depth %d); primary stage %d workgroups/CU, %zu B LDS, %d records staged; "
+            "bounce stages %d workgroups/CU, %zu B LDS, %d records staged\n", s->stack_need4, s->depth, cfg4_rel.blocks_per_cu, cfg4_rel.lds_t,
+            cfg4_rel.lds_nodes, cfg4_abs.blocks_per_cu, cfg4_abs.lds_t, cfg4_abs.lds_nodes);
 
   const Tuning& tu = s->tune;
   const TraceCfg cfg = trace_cfg(s);

@@ -80,8 +80,11 @@ __global__ void inner4_rel_kernel(const float4* in, int n, float sx, float sy, f
   o[7] = r[7];
 }
 
-template <int WPS, bool REL>
+// DLDS (only without REL): ray directions in LDS columns instead of VGPRs (see lds_dir below); chosen by the host when
+// the tree's stack rows leave room for them next to a useful number of staged records
+template <int WPS, bool REL, bool DLDS = false>
 __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
+  static_assert(!(REL && DLDS), "the primary stage's variant keeps its directions in registers");
   extern __shared__ __attribute__((aligned(16))) int lds_stack[];
   const TraceQArgs& a = A.q;
   int* stack = lds_stack + threadIdx.x;
@@ -90,13 +93,13 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
   const int lane = threadIdx.x & 63;
   if (n_rays == 0) return;
   int* wsrc = lds_stack + a.stack_entries * BLOCK + (threadIdx.x >> 6) * 64;
-  // !REL: the ray direction lives in LDS (three BLOCK-float columns after the lane table), not in VGPRs: it is only
+  // DLDS: the ray direction lives in LDS (three BLOCK-float columns after the lane table), not in VGPRs: it is only
   // read in the leaf and steal phases -- by OTHER lanes, through what used to be shuffles -- and the three registers
   // are the difference between spilling loop invariants and not (80-VGPR budget)
   float* lds_dir = reinterpret_cast<float*>(lds_stack + a.stack_entries * BLOCK + BLOCK);
   float* my_dir = lds_dir + threadIdx.x;
   float* wave_dir = lds_dir + (threadIdx.x & ~63);
-  float4* lds_nodes = reinterpret_cast<float4*>(lds_stack + a.stack_entries * BLOCK + BLOCK + (REL ? 0 : 3 * BLOCK));
+  float4* lds_nodes = reinterpret_cast<float4*>(lds_stack + a.stack_entries * BLOCK + BLOCK + (DLDS ? 3 * BLOCK : 0));
   const float4* inner = REL ? A.inner4_rel : A.inner4;
   for (int k = threadIdx.x; k < A.lds_nodes4 * 7; k += BLOCK) lds_nodes[k] = inner[(k / 7) * N4_FLOAT4 + (k % 7)];
   __syncthreads();
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
           // it, no prefetched origin, none of its shuffles in the leaf and steal phases (7 VGPRs less at a budget of 80)
           S = REL ? mk(a.origin[0], a.origin[1], a.origin[2]) : mk(nx_o.x, nx_o.y, nx_o.z);
           d = mk(nx_d.x, nx_d.y, nx_d.z);
-          if (!REL) {
+          if (DLDS) {
             my_dir[0] = d.x;
             my_dir[BLOCK] = d.y;
             my_dir[2 * BLOCK] = d.z;
@@ -271,14 +274,14 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
           const uint32_t vslot = (uint32_t)__shfl((int)slot, src, 64);
           const float vsx = REL ? a.origin[0] : __shfl(S.x, src, 64), vsy = REL ? a.origin[1] : __shfl(S.y, src, 64),
                       vsz = REL ? a.origin[2] : __shfl(S.z, src, 64);
-          const float vdx = REL ? __shfl(d.x, src, 64) : wave_dir[src], vdy = REL ? __shfl(d.y, src, 64) : wave_dir[BLOCK + src],
-                      vdz = REL ? __shfl(d.z, src, 64) : wave_dir[2 * BLOCK + src];
+          const float vdx = !DLDS ? __shfl(d.x, src, 64) : wave_dir[src], vdy = !DLDS ? __shfl(d.y, src, 64) : wave_dir[BLOCK + src],
+                      vdz = !DLDS ? __shfl(d.z, src, 64) : wave_dir[2 * BLOCK + src];
           if (thief) {
             shared = true;
             slot = vslot;
             S = mk(vsx, vsy, vsz);
             d = mk(vdx, vdy, vdz);
-            if (!REL) {
+            if (DLDS) {
               my_dir[0] = vdx;
               my_dir[BLOCK] = vdy;
               my_dir[2 * BLOCK] = vdz;
@@ -439,8 +442,8 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
           const int src = helper ? wsrc[grp] : lane;
           const f3 cS = REL ? mk(a.origin[0], a.origin[1], a.origin[2])
                             : mk(__shfl(S.x, src, 64), __shfl(S.y, src, 64), __shfl(S.z, src, 64));
-          const f3 cd = REL ? mk(__shfl(d.x, src, 64), __shfl(d.y, src, 64), __shfl(d.z, src, 64))
-                            : mk(wave_dir[src], wave_dir[BLOCK + src], wave_dir[2 * BLOCK + src]);
+          const f3 cd = !DLDS ? mk(__shfl(d.x, src, 64), __shfl(d.y, src, 64), __shfl(d.z, src, 64))
+                              : mk(wave_dir[src], wave_dir[BLOCK + src], wave_dir[2 * BLOCK + src]);
           const uint32_t lref = (uint32_t)__shfl((int)ref, src, 64);
           unsigned long long key = ~0ull;
           if (helper) {
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
           for (int i = first; i < first + n; i++) {
             float t;
             if (hit_triangle_t(sc.tri_geom + (size_t)i * 3, REL ? mk(a.origin[0], a.origin[1], a.origin[2]) : S,
-                               REL ? d : mk(my_dir[0], my_dir[BLOCK], my_dir[2 * BLOCK]), t))
+                               !DLDS ? d : mk(my_dir[0], my_dir[BLOCK], my_dir[2 * BLOCK]), t))
               take(t, i);
           }
         }
