@@ -87,19 +87,21 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
   static_assert(!(REL && DLDS), "the primary stage's variant keeps its directions in registers");
   extern __shared__ __attribute__((aligned(16))) int lds_stack[];
   const TraceQArgs& a = A.q;
-  int* stack = lds_stack + threadIdx.x;
+  // LDS layout: [lane table: BLOCK ints][DLDS: direction columns, 3 x BLOCK floats][stack rows][staged records] -- the
+  // per-lane columns first, at compile-time offsets from ONE per-lane address (fewer loop-invariant VGPRs)
+  int* stack = lds_stack + BLOCK + (DLDS ? 3 * BLOCK : 0) + threadIdx.x;
   const DevScene& sc = a.sc;
   const uint32_t n_rays = (*a.n_paths) * a.rays_per_path;
   const int lane = threadIdx.x & 63;
   if (n_rays == 0) return;
-  int* wsrc = lds_stack + a.stack_entries * BLOCK + (threadIdx.x >> 6) * 64;
+  int* wsrc = lds_stack + (threadIdx.x >> 6) * 64;
   // DLDS: the ray direction lives in LDS (three BLOCK-float columns after the lane table), not in VGPRs: it is only
   // read in the leaf and steal phases -- by OTHER lanes, through what used to be shuffles -- and the three registers
   // are the difference between spilling loop invariants and not (80-VGPR budget)
-  float* lds_dir = reinterpret_cast<float*>(lds_stack + a.stack_entries * BLOCK + BLOCK);
+  float* lds_dir = reinterpret_cast<float*>(lds_stack + BLOCK);
   float* my_dir = lds_dir + threadIdx.x;
   float* wave_dir = lds_dir + (threadIdx.x & ~63);
-  float4* lds_nodes = reinterpret_cast<float4*>(lds_stack + a.stack_entries * BLOCK + BLOCK + (DLDS ? 3 * BLOCK : 0));
+  float4* lds_nodes = reinterpret_cast<float4*>(lds_stack + BLOCK + (DLDS ? 3 * BLOCK : 0) + a.stack_entries * BLOCK);
   const float4* inner = REL ? A.inner4_rel : A.inner4;
   for (int k = threadIdx.x; k < A.lds_nodes4 * 7; k += BLOCK) lds_nodes[k] = inner[(k / 7) * N4_FLOAT4 + (k % 7)];
   __syncthreads();
