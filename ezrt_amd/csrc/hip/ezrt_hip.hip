@@ -830,12 +830,16 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
         for (size_t i = 0; i < nw; i++)
           if (w[i * 8] && w[i * 8] < t0) t0 = w[i * 8];
         unsigned long long s_it = 0, s_is = 0, s_il = 0, s_ll = 0, s_lr = 0, s_busy = 0, s_rf = 0, s_st = 0;
-        std::vector<double> endt, life, its, rays, startt;
+        std::vector<double> endt, life, its, rays, startt, exht, after;
         for (size_t i = 0; i < nw; i++)
           if (w[i * 8]) {
             startt.push_back((double)(w[i * 8] - t0) * 0.01);
             endt.push_back((double)(w[i * 8 + 1] - t0) * 0.01);
             life.push_back((double)(w[i * 8 + 1] - w[i * 8]) * 0.01);
+            if (w[i * 8 + 7]) {
+              exht.push_back((double)(w[i * 8 + 7] - t0) * 0.01);
+              after.push_back((double)(w[i * 8 + 1] - w[i * 8 + 7]) * 0.01);
+            }
             its.push_back((double)(uint32_t)w[i * 8 + 2]);
             rays.push_back((double)(uint32_t)w[i * 8 + 3]);
             s_it += (uint32_t)w[i * 8 + 2];
@@ -859,6 +863,9 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
         fprintf(stderr, "[ezrt]   iterations %llu: lanes with a ray %.1f/64 | inner steps in %.0f %% of them, %.1f lanes each | cooperative leaf rounds in %.0f %%, %.1f rays each\n",
                 s_it, (double)s_busy / (double)(s_it ? s_it : 1), 100.0 * (double)s_is / (double)(s_it ? s_it : 1), (double)s_il / (double)(s_is ? s_is : 1),
                 100.0 * (double)s_lr / (double)(s_it ? s_it : 1), (double)s_ll / (double)(s_lr ? s_lr : 1));
+        if (!exht.empty())
+          fprintf(stderr, "[ezrt]   queue found empty at us p10 %.1f p50 %.1f p90 %.1f max %.1f | a wave then runs on for us p10 %.1f p50 %.1f p90 %.1f max %.1f\n",
+                  pct(exht, 0.1), pct(exht, 0.5), pct(exht, 0.9), pct(exht, 1.0), pct(after, 0.1), pct(after, 0.5), pct(after, 0.9), pct(after, 1.0));
         fprintf(stderr, "[ezrt]   refill block in %.0f %% of the iterations, steal block in %.0f %%\n", 100.0 * (double)s_rf / (double)(s_it ? s_it : 1),
                 100.0 * (double)s_st / (double)(s_it ? s_it : 1));
       }

@@ -167,6 +167,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
   };
 
   const unsigned long long t_start = a.wave_log ? wall_clock64() : 0ull;
+  unsigned long long t_exhausted = 0ull; // (debug_stages=2) when this wave first found the queue empty
   uint32_t wave_iters = 0, dbg_inner_lanes = 0, dbg_inner_steps = 0, dbg_leaf_lanes = 0, dbg_leaf_rounds = 0, dbg_busy_lanes = 0,
            dbg_refills = 0, dbg_steals = 0;
   for (;;) {
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
       }
     }
     if (!ballot((ref & nx_slot) != REF_NONE)) break;
+    if (a.wave_log && exhausted && !t_exhausted) t_exhausted = wall_clock64();
 
     // ---- work stealing: lanes with nothing left to fetch take the oldest pending subtree of a busy lane
     if (a.steal && exhausted) {
@@ -498,6 +500,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
     w[4] = dbg_leaf_lanes | ((unsigned long long)dbg_leaf_rounds << 32);
     w[5] = dbg_busy_lanes;
     w[6] = dbg_refills | ((unsigned long long)dbg_steals << 32);
+    w[7] = t_exhausted;
   }
 }
 
