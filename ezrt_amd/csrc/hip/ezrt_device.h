@@ -63,6 +63,8 @@ struct DevScene {
   const float4* tri_geom;
   const float* tri_ref;
   const float4* inner;
+  const float4* tri_shade; // 4 x float4 per triangle: what a WINNING hit needs besides tri_geom (see ShadeRec below)
+  const float4* mat_table; // 7 x float4 per distinct material: its 18 floats + the constants brdf_evaluate derives from them
   uint32_t root_ref;
   int32_t n_tri;
   const float4* hdr;   // RGBA texels, row 0 = top
@@ -317,6 +319,15 @@ struct Mat {
   f3 emissive, baseColor;
   float subsurface, metallic, specular, specularTint, roughness, anisotropic;
   float sheen, sheenTint, clearcoat, clearcoatGloss;
+  // Sub-expressions of BRDF_Evaluate / SampleBRDF / BRDF_Pdf that depend on the material alone (P5/fsh:446-451, 468,
+  // 486, 636-637, 727-728), evaluated ONCE per distinct material by mat_derive -- the same fp32 operations in the same
+  // order, on the host at ezrt_scene_create (contraction off, ez_log from the shared header: bit-identical to the
+  // device, tests/test_gpu_parity.py) -- instead of once per shaded hit: three divisions, a logarithm, seven mixes
+  f3 Cspec0, Csheen;
+  float alpha_gtr2;   // max(0.001, sqr(roughness))
+  float alpha_gtr1;   // mix(0.1, 0.001, clearcoatGloss)
+  float gtr1_a2m1;    // a2 - 1,         a2 = alpha_gtr1^2      (GTR1, P5/fsh:410-415)
+  float gtr1_pilog;   // PI * log(a2)
 };
 struct Hit {
   f3 P, N, viewDir;
@@ -324,6 +335,37 @@ struct Hit {
 };
 
 EZD f3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
+
+__host__ __device__ inline void mat_derive(Mat& m) {
+  const float Cdlum = 0.3f * m.baseColor.x + 0.6f * m.baseColor.y + 0.1f * m.baseColor.z;
+  const float tx = (Cdlum > 0.0f) ? m.baseColor.x / Cdlum : 1.0f, ty = (Cdlum > 0.0f) ? m.baseColor.y / Cdlum : 1.0f,
+              tz = (Cdlum > 0.0f) ? m.baseColor.z / Cdlum : 1.0f;                                  // Ctint
+  const float sx = ez_mix(1.0f, tx, m.specularTint) * m.specular, sy = ez_mix(1.0f, ty, m.specularTint) * m.specular,
+              sz = ez_mix(1.0f, tz, m.specularTint) * m.specular;                                  // Cspec
+  m.Cspec0 = f3{ez_mix(sx * 0.08f, m.baseColor.x, m.metallic), ez_mix(sy * 0.08f, m.baseColor.y, m.metallic),
+                ez_mix(sz * 0.08f, m.baseColor.z, m.metallic)};
+  m.Csheen = f3{ez_mix(1.0f, tx, m.sheenTint), ez_mix(1.0f, ty, m.sheenTint), ez_mix(1.0f, tz, m.sheenTint)};
+  m.alpha_gtr2 = ez_max(0.001f, m.roughness * m.roughness);
+  m.alpha_gtr1 = ez_mix(0.1f, 0.001f, m.clearcoatGloss);
+  const float a2 = m.alpha_gtr1 * m.alpha_gtr1;
+  m.gtr1_a2m1 = a2 - 1.0f;
+  m.gtr1_pilog = EZ_PI * ez_log(a2);
+}
+
+// What a winning hit reads besides the 48-byte tri_geom record: 64 B per triangle, four aligned 16-byte loads
+// (the reference record's texels 3-11 were seven, P5/fsh:110-135, 199-214):
+//   (n1.xyz, n2.x) (n2.yz, n3.xy) (n3.z, bits(material index), -, -) (alpha and beta denominators of the smooth-normal
+//   interpolation, P5/fsh:206-207 form and P3/fsh:273-274 form: functions of the triangle alone)
+constexpr int SHADE_REC_FLOAT4 = 4, MAT_REC_FLOAT4 = 7;
+struct ShadeDen { float a5, b5, a34, b34; };
+__host__ __device__ inline ShadeDen shade_denominators(f3 p1, f3 p2, f3 p3) {
+  ShadeDen d;
+  d.a5 = -(p1.x - p2.x) * (p3.y - p2.y) + (p1.y - p2.y) * (p3.x - p2.x) + 1e-7f;
+  d.b5 = -(p2.x - p3.x) * (p1.y - p3.y) + (p2.y - p3.y) * (p1.x - p3.x) + 1e-7f;
+  d.a34 = -(p1.x - p2.x - 0.00005f) * (p3.y - p2.y + 0.00005f) + (p1.y - p2.y + 0.00005f) * (p3.x - p2.x + 0.00005f);
+  d.b34 = -(p2.x - p3.x - 0.00005f) * (p1.y - p3.y + 0.00005f) + (p2.y - p3.y + 0.00005f) * (p1.x - p3.x + 0.00005f);
+  return d;
+}
 
 template <bool P5TRI>
 EZD void shade_point(const DevScene& sc, int32_t tri, float t, f3 S, f3 d, Hit& h) {
@@ -333,39 +375,43 @@ EZD void shade_point(const DevScene& sc, int32_t tri, float t, f3 S, f3 d, Hit& 
   f3 N = mk(a.w, b.w, c.w);
   bool inside = dot(N, d) > 0.0f;
   f3 P = S + d * t;
-  // texels 3-11 of the reference record (floats 9..35) as seven aligned 16-B loads
-  const float4* rq = reinterpret_cast<const float4*>(sc.tri_ref + (size_t)tri * 36);
-  const float4 r2 = rq[2], r3 = rq[3], r4 = rq[4], r5 = rq[5], r6 = rq[6], r7 = rq[7], r8 = rq[8];
-  f3 n1 = mk(r2.y, r2.z, r2.w), n2 = mk(r3.x, r3.y, r3.z), n3 = mk(r3.w, r4.x, r4.y);
+  const float4* rq = sc.tri_shade + (size_t)tri * SHADE_REC_FLOAT4;
+  const float4 r0 = rq[0], r1 = rq[1], r2 = rq[2], r3 = rq[3];
+  f3 n1 = mk(r0.x, r0.y, r0.z), n2 = mk(r0.w, r1.x, r1.y), n3 = mk(r1.z, r1.w, r2.x);
+  const float4* mq = sc.mat_table + (size_t)__float_as_uint(r2.y) * MAT_REC_FLOAT4;
+  const float4 m0 = mq[0], m1 = mq[1], m2 = mq[2], m3 = mq[3], m4 = mq[4], m5 = mq[5], m6 = mq[6];
   float alpha, beta;
   if (P5TRI) { // P5/fsh:206-207
-    alpha = (-(P.x - p2.x) * (p3.y - p2.y) + (P.y - p2.y) * (p3.x - p2.x)) /
-            (-(p1.x - p2.x) * (p3.y - p2.y) + (p1.y - p2.y) * (p3.x - p2.x) + 1e-7f);
-    beta = (-(P.x - p3.x) * (p1.y - p3.y) + (P.y - p3.y) * (p1.x - p3.x)) /
-           (-(p2.x - p3.x) * (p1.y - p3.y) + (p2.y - p3.y) * (p1.x - p3.x) + 1e-7f);
+    alpha = (-(P.x - p2.x) * (p3.y - p2.y) + (P.y - p2.y) * (p3.x - p2.x)) / r3.x;
+    beta = (-(P.x - p3.x) * (p1.y - p3.y) + (P.y - p3.y) * (p1.x - p3.x)) / r3.y;
   } else { // P3/fsh:273-274, P4/fsh:196-197
-    alpha = (-(P.x - p2.x) * (p3.y - p2.y) + (P.y - p2.y) * (p3.x - p2.x)) /
-            (-(p1.x - p2.x - 0.00005f) * (p3.y - p2.y + 0.00005f) + (p1.y - p2.y + 0.00005f) * (p3.x - p2.x + 0.00005f));
-    beta = (-(P.x - p3.x) * (p1.y - p3.y) + (P.y - p3.y) * (p1.x - p3.x)) /
-           (-(p2.x - p3.x - 0.00005f) * (p1.y - p3.y + 0.00005f) + (p2.y - p3.y + 0.00005f) * (p1.x - p3.x + 0.00005f));
+    alpha = (-(P.x - p2.x) * (p3.y - p2.y) + (P.y - p2.y) * (p3.x - p2.x)) / r3.z;
+    beta = (-(P.x - p3.x) * (p1.y - p3.y) + (P.y - p3.y) * (p1.x - p3.x)) / r3.w;
   }
   float gama = 1.0f - alpha - beta;
   f3 Ns = normalize(n1 * alpha + n2 * beta + n3 * gama);
   h.P = P;
   h.N = inside ? -Ns : Ns;
   h.viewDir = d;
-  h.m.emissive = mk(r4.z, r4.w, r5.x);
-  h.m.baseColor = mk(r5.y, r5.z, r5.w);
-  h.m.subsurface = r6.x;
-  h.m.metallic = r6.y;
-  h.m.specular = r6.z;
-  h.m.specularTint = r6.w;
-  h.m.roughness = r7.x;
-  h.m.anisotropic = r7.y;
-  h.m.sheen = r7.z;
-  h.m.sheenTint = r7.w;
-  h.m.clearcoat = r8.x;
-  h.m.clearcoatGloss = r8.y;
+  h.m.emissive = mk(m0.x, m0.y, m0.z);
+  h.m.baseColor = mk(m0.w, m1.x, m1.y);
+  h.m.subsurface = m1.z;
+  h.m.metallic = m1.w;
+  h.m.specular = m2.x;
+  h.m.specularTint = m2.y;
+  h.m.roughness = m2.z;
+  h.m.anisotropic = m2.w;
+  h.m.sheen = m3.x;
+  h.m.sheenTint = m3.y;
+  h.m.clearcoat = m3.z;
+  h.m.clearcoatGloss = m3.w;
+  // (m4.x, m4.y = IOR, transmission: carried by the reference, read by no shader)
+  h.m.Cspec0 = mk(m4.z, m4.w, m5.x);
+  h.m.Csheen = mk(m5.y, m5.z, m5.w);
+  h.m.alpha_gtr2 = m6.x;
+  h.m.alpha_gtr1 = m6.y;
+  h.m.gtr1_a2m1 = m6.z;
+  h.m.gtr1_pilog = m6.w;
 }
 
 // ---------------------------------------------------------------------------
@@ -496,6 +542,12 @@ EZD float gtr1(float NdotH, float a) {
   float t = 1.0f + (a2 - 1.0f) * NdotH * NdotH;
   return (a2 - 1.0f) / (PI * ez_log(a2) * t);
 }
+// the same with the material's precomputed a2 - 1 and PI * log(a2) (Mat)
+EZD float gtr1_m(float NdotH, const Mat& m) {
+  if (m.alpha_gtr1 >= 1.0f) return 1.0f / PI;
+  float t = 1.0f + m.gtr1_a2m1 * NdotH * NdotH;
+  return m.gtr1_a2m1 / (m.gtr1_pilog * t);
+}
 EZD float gtr2(float NdotH, float a) {
   float a2 = a * a;
   float t = 1.0f + (a2 - 1.0f) * NdotH * NdotH;
@@ -520,13 +572,8 @@ EZD f3 brdf_evaluate(f3 V, f3 N, f3 L, f3 X, f3 Y, const Mat& m) {
   f3 H = normalize(L + V);
   float NdotH = dot(N, H), LdotH = dot(L, H);
 
-  f3 Cdlin = m.baseColor;
-  float Cdlum = 0.3f * Cdlin.x + 0.6f * Cdlin.y + 0.1f * Cdlin.z;
-  f3 one = mk(1, 1, 1);
-  f3 Ctint = (Cdlum > 0.0f) ? (Cdlin / Cdlum) : one;
-  f3 Cspec = mix3(one, Ctint, m.specularTint) * m.specular;
-  f3 Cspec0 = mix3(Cspec * 0.08f, Cdlin, m.metallic);
-  f3 Csheen = mix3(one, Ctint, m.sheenTint);
+  // Cdlum, Ctint, Cspec, Cspec0, Csheen (P5/fsh:446-451): functions of the material alone -> Mat (mat_derive)
+  const f3 Cdlin = m.baseColor, one = mk(1, 1, 1), Cspec0 = m.Cspec0, Csheen = m.Csheen;
 
   float Fd90 = 0.5f + 2.0f * LdotH * LdotH * m.roughness;
   float FL = schlick(NdotL), FV = schlick(NdotV);
@@ -540,8 +587,7 @@ EZD f3 brdf_evaluate(f3 V, f3 N, f3 L, f3 X, f3 Y, const Mat& m) {
   float FH = schlick(LdotH);
   f3 Fs = mix3(Cspec0, one, FH);
   if (!ANISO) {
-    float alpha = ez_max(0.001f, sqr(m.roughness));
-    Ds = gtr2(NdotH, alpha);
+    Ds = gtr2(NdotH, m.alpha_gtr2);
     Gs = smith_ggx(NdotL, m.roughness);
     Gs *= smith_ggx(NdotV, m.roughness);
   } else {
@@ -552,7 +598,7 @@ EZD f3 brdf_evaluate(f3 V, f3 N, f3 L, f3 X, f3 Y, const Mat& m) {
     Gs = smith_ggx_aniso(NdotL, dot(L, X), dot(L, Y), ax, ay);
     Gs *= smith_ggx_aniso(NdotV, dot(V, X), dot(V, Y), ax, ay);
   }
-  float Dr = gtr1(NdotH, ez_mix(0.1f, 0.001f, m.clearcoatGloss));
+  float Dr = gtr1_m(NdotH, m);
   float Fr = ez_mix(0.04f, 1.0f, FH);
   float Gr = smith_ggx(NdotL, 0.25f) * smith_ggx(NdotV, 0.25f);
 
@@ -609,8 +655,7 @@ EZD f3 sample_gtr(float xi1, f3 V, f3 N, float cos_theta_h) {
 }
 // SampleBRDF: P5/fsh:633-664
 EZD f3 sample_brdf(float xi1, float xi2, float xi3, f3 V, f3 N, const Mat& m) {
-  float alpha_GTR1 = ez_mix(0.1f, 0.001f, m.clearcoatGloss);
-  float alpha_GTR2 = ez_max(0.001f, sqr(m.roughness));
+  const float alpha_GTR1 = m.alpha_gtr1, alpha_GTR2 = m.alpha_gtr2;
   float r_diffuse = 1.0f - m.metallic;
   float r_specular = 1.0f;
   float r_clearcoat = 0.25f * m.clearcoat;
@@ -635,9 +680,8 @@ EZD float brdf_pdf(f3 V, f3 N, f3 L, const Mat& m) {
   if (NdotL < 0.0f || NdotV < 0.0f) return 0.0f;
   f3 H = normalize(L + V);
   float NdotH = dot(N, H), LdotH = dot(L, H);
-  float alpha = ez_max(0.001f, sqr(m.roughness));
-  float Ds = gtr2(NdotH, alpha);
-  float Dr = gtr1(NdotH, ez_mix(0.1f, 0.001f, m.clearcoatGloss));
+  float Ds = gtr2(NdotH, m.alpha_gtr2);
+  float Dr = gtr1_m(NdotH, m);
   float pdf_diffuse = NdotL / PI;
   float pdf_specular = Ds * NdotH / (4.0f * LdotH);
   float pdf_clearcoat = Dr * NdotH / (4.0f * LdotH);
@@ -674,7 +718,7 @@ EZD f3 sample_gtr2_aniso(float xi1, float xi2, f3 V, f3 N, f3 X, f3 Y, float ax,
   return reflect(-V, H);
 }
 EZD f3 sample_brdf_aniso(float xi1, float xi2, float xi3, f3 V, f3 N, f3 X, f3 Y, const Mat& m) {
-  float alpha_GTR1 = ez_mix(0.1f, 0.001f, m.clearcoatGloss);
+  const float alpha_GTR1 = m.alpha_gtr1;
   float ax, ay;
   aniso_alphas(m, ax, ay);
   float r_diffuse = 1.0f - m.metallic;
@@ -700,7 +744,7 @@ EZD float brdf_pdf_aniso(f3 V, f3 N, f3 L, f3 X, f3 Y, const Mat& m) {
   float ax, ay;
   aniso_alphas(m, ax, ay);
   float Ds = gtr2_aniso(NdotH, dot(H, X), dot(H, Y), ax, ay);
-  float Dr = gtr1(NdotH, ez_mix(0.1f, 0.001f, m.clearcoatGloss));
+  float Dr = gtr1_m(NdotH, m);
   float pdf_diffuse = NdotL / PI;
   float pdf_specular = Ds * NdotH / (4.0f * LdotH);
   float pdf_clearcoat = Dr * NdotH / (4.0f * LdotH);

@@ -7,7 +7,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <array>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -175,6 +177,8 @@ struct Pipe {
 struct EzrtScene {
   int n_tri = 0, n_nodes = 0;
   DevBuf<float4> tri_geom;
+  DevBuf<float4> tri_shade, mat_table; // per-triangle shading records, distinct materials (ezrt_device.h: shade_point)
+  int n_materials = 0;
   DevBuf<float> tri_ref;
   DevBuf<float4> inner;
   DevBuf<float4> inner4;      // 4-wide records (ezrt_traceq4.h), breadth-first; empty when the boxes are not nested
@@ -215,6 +219,8 @@ struct EzrtScene {
     DevScene d;
     d.tri_geom = tri_geom.p;
     d.tri_ref = tri_ref.p;
+    d.tri_shade = tri_shade.p;
+    d.mat_table = mat_table.p;
     d.inner = inner.p;
     d.root_ref = root_ref;
     d.n_tri = n_tri;
@@ -438,16 +444,21 @@ bool use_wide4(const EzrtScene* s) {
   return s->tune.wide4 && s->n_inner4 > 0 && s->instr == 0 &&
          ((size_t)s->stack_need4 + 1) * BLOCK * sizeof(int) <= 60 * 1024; // stack rows + lane table
 }
-template <bool REL, bool DLDS>
-void launch_traceq4_rel(EzrtScene* s, const TraceCfg& c, const TraceQ4Args& q, hipStream_t st) {
+template <bool REL, bool DLDS, bool LOG>
+void launch_traceq4_v(EzrtScene* s, const TraceCfg& c, const TraceQ4Args& q, hipStream_t st) {
   const int trace_wps = wps4(s, REL);
   const dim3 grid(c.grid_full), block(BLOCK);
-  if (trace_wps == 8) hipLaunchKernelGGL((traceq4_kernel<8, REL, DLDS>), grid, block, c.lds_t, st, q);
-  else if (trace_wps == 7) hipLaunchKernelGGL((traceq4_kernel<7, REL, DLDS>), grid, block, c.lds_t, st, q);
-  else if (trace_wps == 6) hipLaunchKernelGGL((traceq4_kernel<6, REL, DLDS>), grid, block, c.lds_t, st, q);
-  else if (trace_wps == 4) hipLaunchKernelGGL((traceq4_kernel<4, REL, DLDS>), grid, block, c.lds_t, st, q);
-  else hipLaunchKernelGGL((traceq4_kernel<5, REL, DLDS>), grid, block, c.lds_t, st, q);
+  if (trace_wps == 8) hipLaunchKernelGGL((traceq4_kernel<8, REL, DLDS, LOG>), grid, block, c.lds_t, st, q);
+  else if (trace_wps == 7) hipLaunchKernelGGL((traceq4_kernel<7, REL, DLDS, LOG>), grid, block, c.lds_t, st, q);
+  else if (trace_wps == 6) hipLaunchKernelGGL((traceq4_kernel<6, REL, DLDS, LOG>), grid, block, c.lds_t, st, q);
+  else if (trace_wps == 4) hipLaunchKernelGGL((traceq4_kernel<4, REL, DLDS, LOG>), grid, block, c.lds_t, st, q);
+  else hipLaunchKernelGGL((traceq4_kernel<5, REL, DLDS, LOG>), grid, block, c.lds_t, st, q);
   s->n_trace_launches++;
+}
+template <bool REL, bool DLDS>
+void launch_traceq4_rel(EzrtScene* s, const TraceCfg& c, const TraceQ4Args& q, hipStream_t st) {
+  if (q.q.wave_log) launch_traceq4_v<REL, DLDS, true>(s, c, q, st); // (debug_stages=2)
+  else launch_traceq4_v<REL, DLDS, false>(s, c, q, st);
 }
 // t: the stage's queue arguments as for the binary kernel (knobs already filled); rel: 4-wide records translated by
 // t.origin (or NULL)
@@ -666,7 +677,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
       break;
     }
     TraceQArgs t;
-    t.sc = a.sc;
+    t.sc = trace_scene(a.sc);
     t.rq = queue(in);
     t.hits = pp.hits2[in].p;
     t.n_paths = pp.qcounts.p + b;
@@ -1132,9 +1143,55 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
     geom[(size_t)i * 3 + 2] = make_float4(t[6], t[7], t[8], cz * inv);
   }
 
+  // ---- shading records + table of distinct materials (bitwise distinct 18-float tuples)
+  std::vector<float4> shade((size_t)n_tri * SHADE_REC_FLOAT4), mats;
+  {
+    std::map<std::array<uint32_t, 18>, uint32_t> index;
+    for (int i = 0; i < n_tri; i++) {
+      const float* t = tri + (size_t)i * EZRT_TRI_FLOATS;
+      std::array<uint32_t, 18> key;
+      memcpy(key.data(), t + 18, sizeof(uint32_t) * 18);
+      auto it = index.find(key);
+      if (it == index.end()) {
+        it = index.emplace(key, (uint32_t)index.size()).first;
+        Mat m;
+        m.emissive = f3{t[18], t[19], t[20]};
+        m.baseColor = f3{t[21], t[22], t[23]};
+        m.subsurface = t[24];
+        m.metallic = t[25];
+        m.specular = t[26];
+        m.specularTint = t[27];
+        m.roughness = t[28];
+        m.anisotropic = t[29];
+        m.sheen = t[30];
+        m.sheenTint = t[31];
+        m.clearcoat = t[32];
+        m.clearcoatGloss = t[33];
+        mat_derive(m);
+        mats.push_back(make_float4(t[18], t[19], t[20], t[21]));
+        mats.push_back(make_float4(t[22], t[23], t[24], t[25]));
+        mats.push_back(make_float4(t[26], t[27], t[28], t[29]));
+        mats.push_back(make_float4(t[30], t[31], t[32], t[33]));
+        mats.push_back(make_float4(t[34], t[35], m.Cspec0.x, m.Cspec0.y));
+        mats.push_back(make_float4(m.Cspec0.z, m.Csheen.x, m.Csheen.y, m.Csheen.z));
+        mats.push_back(make_float4(m.alpha_gtr2, m.alpha_gtr1, m.gtr1_a2m1, m.gtr1_pilog));
+      }
+      const ShadeDen dn = shade_denominators(f3{t[0], t[1], t[2]}, f3{t[3], t[4], t[5]}, f3{t[6], t[7], t[8]});
+      float mi;
+      const uint32_t mu = it->second;
+      memcpy(&mi, &mu, 4);
+      float4* o = &shade[(size_t)i * SHADE_REC_FLOAT4];
+      o[0] = make_float4(t[9], t[10], t[11], t[12]);
+      o[1] = make_float4(t[13], t[14], t[15], t[16]);
+      o[2] = make_float4(t[17], mi, 0.0f, 0.0f);
+      o[3] = make_float4(dn.a5, dn.b5, dn.a34, dn.b34);
+    }
+  }
+
   EzrtScene* s = new (std::nothrow) EzrtScene();
   if (!s) return fail(EZRT_ERR_NOMEM, "out of memory");
   s->n_tri = n_tri;
+  s->n_materials = (int)(mats.size() / MAT_REC_FLOAT4);
   s->n_nodes = n_nodes;
   s->depth = maxd;
   s->n_inner = n_inner;
@@ -1152,6 +1209,10 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
   SC_TRY(s->inner.ensure(inner.size()));
   SC_TRY(s->counters.ensure((size_t)CTR_SLOTS * EZRT_CTR_COUNT));
   SC_TRY(hipMemcpy(s->tri_geom.p, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice));
+  SC_TRY(s->tri_shade.ensure(shade.size()));
+  SC_TRY(s->mat_table.ensure(mats.size()));
+  SC_TRY(hipMemcpy(s->tri_shade.p, shade.data(), shade.size() * sizeof(float4), hipMemcpyHostToDevice));
+  SC_TRY(hipMemcpy(s->mat_table.p, mats.data(), mats.size() * sizeof(float4), hipMemcpyHostToDevice));
   SC_TRY(hipMemcpy(s->tri_ref.p, tri, (size_t)n_tri * EZRT_TRI_FLOATS * sizeof(float), hipMemcpyHostToDevice));
   SC_TRY(hipMemcpy(s->inner.p, inner.data(), inner.size() * sizeof(float4), hipMemcpyHostToDevice));
   s->n_inner4 = n_inner4;
@@ -1169,7 +1230,7 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
   s->stats[3] = leaves;
   s->stats[4] = maxleaf;
   s->stats[5] = (int64_t)(geom.size() * sizeof(float4) + (size_t)n_tri * 144 + inner.size() * sizeof(float4) +
-                          inner4.size() * sizeof(float4));
+                          inner4.size() * sizeof(float4) + shade.size() * sizeof(float4) + mats.size() * sizeof(float4));
   *out = s;
   return 0;
 }
@@ -1479,7 +1540,7 @@ int ezrt_query_hits(EzrtScene* s, const float* rays, int n_rays, int32_t* tri_id
     const TraceCfg cfg = trace_cfg(s);
     const bool shared_origin = s->tune.audit_via_queue >= 2;
     TraceQArgs t;
-    t.sc = s->dev();
+    t.sc = trace_scene(s->dev());
     t.rq.o = pp.rq_o[0].p;
     t.rq.d = pp.rq_d[0].p;
     t.hits = pp.hits2[0].p;

@@ -400,6 +400,8 @@ __global__ void isect_kernel(int op, const float* a, const float* b, int n, floa
     m.metallic = q[2];
     m.clearcoat = q[3];
     m.clearcoatGloss = q[4];
+    m.anisotropic = q[1];
+    mat_derive(m);
     const f3 N = mk(0, 0, 1);
     f3 X, Y;
     get_tangent(N, X, Y);

@@ -35,8 +35,17 @@ struct RayQueue {
   float4* d; // dir.xyz, valid (1) / skip (0)
 };
 
+// what hitBVH needs of the scene
+struct TraceScene {
+  const float4* tri_geom;
+  const float4* inner;
+  uint32_t root_ref;
+};
+inline TraceScene trace_scene(const DevScene& d) { return TraceScene{d.tri_geom, d.inner, d.root_ref}; }
+
 struct TraceQArgs {
-  DevScene sc;
+  TraceScene sc; // (not the whole DevScene: every kernel argument a launch carries costs the trace kernels scalar
+                 // registers, and they sit at their VGPR line -- two more pointers in DevScene turned 4 spills into 7)
   RayQueue rq;
   int2* hits;
   const uint32_t* n_paths; // device count; rays = n_paths * rays_per_path
@@ -89,7 +98,7 @@ template <bool FULLCTR, int WPS>
 __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
   extern __shared__ __attribute__((aligned(16))) int lds_stack[];
   int* stack = lds_stack + threadIdx.x;
-  const DevScene& sc = a.sc;
+  const TraceScene& sc = a.sc;
   const uint32_t n_rays = (*a.n_paths) * a.rays_per_path;
   const int lane = threadIdx.x & 63;
   if (n_rays == 0) return; // (redo launches are normally empty)

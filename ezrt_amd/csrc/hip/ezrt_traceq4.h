@@ -82,7 +82,10 @@ __global__ void inner4_rel_kernel(const float4* in, int n, float sx, float sy, f
 
 // DLDS (only without REL): ray directions in LDS columns instead of VGPRs (see lds_dir below); chosen by the host when
 // the tree's stack rows leave room for them next to a useful number of staged records
-template <int WPS, bool REL, bool DLDS = false>
+// LOG: the per-wave diagnostics of debug_stages=2 (a.wave_log).  A template parameter, not a run-time test: the
+// counters and time stamps are loop-carried values, and even never-executed they cost the production kernel registers
+// (one 64-bit time stamp turned 4 spills into 7: -2 %).
+template <int WPS, bool REL, bool DLDS = false, bool LOG = false>
 __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
   static_assert(!(REL && DLDS), "the primary stage's variant keeps its directions in registers");
   extern __shared__ __attribute__((aligned(16))) int lds_stack[];
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
   // LDS layout: [lane table: BLOCK ints][DLDS: direction columns, 3 x BLOCK floats][stack rows][staged records] -- the
   // per-lane columns first, at compile-time offsets from ONE per-lane address (fewer loop-invariant VGPRs)
   int* stack = lds_stack + BLOCK + (DLDS ? 3 * BLOCK : 0) + threadIdx.x;
-  const DevScene& sc = a.sc;
+  const TraceScene& sc = a.sc;
   const uint32_t n_rays = (*a.n_paths) * a.rays_per_path;
   const int lane = threadIdx.x & 63;
   if (n_rays == 0) return;
@@ -166,17 +169,17 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
     }
   };
 
-  const unsigned long long t_start = a.wave_log ? wall_clock64() : 0ull;
+  const unsigned long long t_start = (LOG && a.wave_log) ? wall_clock64() : 0ull;
   unsigned long long t_exhausted = 0ull; // (debug_stages=2) when this wave first found the queue empty
   uint32_t wave_iters = 0, dbg_inner_lanes = 0, dbg_inner_steps = 0, dbg_leaf_lanes = 0, dbg_leaf_rounds = 0, dbg_busy_lanes = 0,
            dbg_refills = 0, dbg_steals = 0;
   for (;;) {
-    wave_iters++;
+    if (LOG) wave_iters++;
     // ---- refill (batched: wave-wide code for per-lane events)
     const bool want = ref >= REF_DONE;
     const unsigned long long wantm = ballot(want);
     if (wantm && ((uint32_t)__popcll(wantm) >= a.refill_min || !ballot(ref < REF_DONE))) {
-      if (a.wave_log) dbg_refills++;
+      if (LOG && a.wave_log) dbg_refills++;
       if (ref == REF_DONE) publish();
       if (want && nx_slot != REF_NONE) {
         const uint32_t adopted = nx_slot;
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
       }
     }
     if (!ballot((ref & nx_slot) != REF_NONE)) break;
-    if (a.wave_log && exhausted && !t_exhausted) t_exhausted = wall_clock64();
+    if (LOG && a.wave_log && exhausted && !t_exhausted) t_exhausted = wall_clock64();
 
     // ---- work stealing: lanes with nothing left to fetch take the oldest pending subtree of a busy lane
     if (a.steal && exhausted) {
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
         const bool rich = sp > sb;
         const unsigned long long vm = ballot(rich);
         if (vm) {
-          if (a.wave_log) dbg_steals++;
+          if (LOG && a.wave_log) dbg_steals++;
           const int ni = (int)__popcll(im), nv = (int)__popcll(vm);
           const int n = ni < nv ? ni : nv;
           const int ir = (int)lane_rank(im), vr = (int)lane_rank(vm);
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
 
     // ---- inner step: four slab tests (hitAABB, P5/fsh:220-233) on one 4-wide record
     const bool at_inner = (int32_t)ref >= 0;
-    if (a.wave_log) {
+    if (LOG && a.wave_log) {
       const uint32_t ni = (uint32_t)__popcll(ballot(at_inner));
       dbg_inner_lanes += ni;
       dbg_inner_steps += ni ? 1u : 0u;
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
           __builtin_amdgcn_wave_barrier();
           const int grp = lane >> (6 - sh), m = lane & (g - 1);
           const bool helper = grp < Lc;
-          if (a.wave_log) {
+          if (LOG && a.wave_log) {
             dbg_leaf_lanes += (uint32_t)Lc;
             dbg_leaf_rounds++;
           }
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
 
   const unsigned long long rr = wave_sum(n_counted);
   if (lane == 0 && rr) atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_RAYS], rr);
-  if (a.wave_log && lane == 0) {
+  if (LOG && a.wave_log && lane == 0) {
     unsigned long long* w = a.wave_log + (size_t)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 8;
     w[0] = t_start;
     w[1] = wall_clock64();
