@@ -164,7 +164,7 @@ struct Pipe {
   DevBuf<uint32_t> qheads;      // traceq reservation counters: [launch slot][TRACE_HEADS][TRACE_HEAD_STRIDE]
   DevBuf<float4> inner_rel;     // inner records translated by -eye (primary rays)
   DevBuf<float4> inner4_rel;    // 4-wide records translated by -eye
-  DevBuf<uint32_t> defer_list;  // split shading: paths with a surface interaction, per workgroup
+  DevBuf<uint4> defer_list;     // split shading: paths with a surface interaction, per workgroup
   DevBuf<uint32_t> defer_count;
   hipStream_t side = nullptr;    // redo launches that overlap the first shading pass
   hipEvent_t ev_main = nullptr;  // a stage's main trace launch is enqueued / done

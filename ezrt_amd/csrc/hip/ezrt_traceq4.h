@@ -137,6 +137,9 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
 
   auto to_redo = [&](uint32_t s) { // (rare) the in-order binary kernel decides this ray
     if (atomicExch(&a.redo_flag[s], 1u) == 0u) a.redo_slots[atomicAdd(a.redo_count, 1u)] = s;
+    // until it has, the record says so: key (t bits 0, tri HIT_PENDING) is below every real key, so later atomicMin
+    // contributions of a split ray cannot replace it; the redo launch overwrites it with a plain store
+    atomicMin(&hits64[s], (unsigned long long)(uint32_t)HIT_PENDING);
   };
   auto finish = [&]() {
     ref = REF_DONE;

@@ -60,7 +60,9 @@ struct WfArgs {
   const float* sobol_tab;  // [frame - frame_first][16]: sobol(d, grayCode(frame + 1)), filled by raygen_kernel
   float* sobol_out;        // (the same table, as raygen_kernel writes it)
   uint32_t n_frames;       // frames of the chunk
-  uint32_t* defer_list;    // split shading: per workgroup of shade_miss_kernel, the paths with a surface interaction
+  uint4* defer_list;       // split shading: per workgroup of shade_miss_kernel, the paths with a surface interaction: (queue
+                           // position, hit triangle, bits(t), shadow ray's hit triangle) -- the second pass starts from the entry,
+                           // not from another dependent read of the hit records (HIT_PENDING entries excepted: those it re-reads)
   uint32_t* defer_count;   // ... and how many; shaded by the same workgroup index of shade_hit_kernel
   FastDiv div_blocks;      // division by n_blocks
   FastDiv div_sub;         // division by the queue granules per frame, (n_blocks * 256) >> scatter_shift
@@ -207,8 +209,9 @@ struct ShadeIn { // what stage b reads for one path (from the queues, or from re
   float4 rd4, ro4, s0, s1, s2, s3, s4;
   int2 h, sh;
 };
+// entry (PASS 2 of the split kernels, or NULL): the list entry shade_miss_kernel wrote for this path
 template <int INTEG, int PASS, int STAGE>
-EZD void shade_load(const WfArgs& a, const uint32_t i, const bool live, ShadeIn& in) {
+EZD void shade_load(const WfArgs& a, const uint32_t i, const bool live, ShadeIn& in, const uint4* entry = nullptr) {
   constexpr bool MIS = integ_mis<INTEG>();
   constexpr bool B0 = (STAGE == 0);
   constexpr bool COMPACT = compact_state<INTEG>();
@@ -219,7 +222,8 @@ EZD void shade_load(const WfArgs& a, const uint32_t i, const bool live, ShadeIn&
   const uint32_t ii = live ? i : 0u;
   const uint32_t rslot = (b == 0 || !MIS) ? ii : (2u * ii + 1u);
   float4 rd4 = a.rq_in.d[rslot];
-  int2 h = a.hits[rslot];
+  const bool from_entry = PASS == 2 && entry && (int32_t)entry->y != HIT_PENDING && (!MIS || (int32_t)entry->w != HIT_PENDING);
+  int2 h = from_entry ? make_int2((int32_t)entry->y, (int32_t)entry->z) : a.hits[rslot];
   float4 ro4 = make_float4(p.eye[0], p.eye[1], p.eye[2], 0.0f);
   float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, s3 = s0, s4 = s0;
   int2 sh = make_int2(-1, 0);
@@ -236,7 +240,7 @@ EZD void shade_load(const WfArgs& a, const uint32_t i, const bool live, ShadeIn&
     if (!COMPACT || STAGE >= 2) s2 = a.st_in.s2[ii];
     if (MIS) {
       s4 = a.st_in.s4[ii];
-      sh = a.hits[2u * ii];
+      sh = from_entry ? make_int2((int32_t)entry->w, 0) : a.hits[2u * ii];
     }
   }
   // Pin the loads here: left alone, the compiler sinks every one of them into the branch that first uses
@@ -544,7 +548,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MISS_WAVES) void shade_miss_kern
   const uint32_t n_in = B0 ? a.n_slots : *a.n_in;
   const uint32_t stride = gridDim.x * SHADE_BLOCK;
   const uint32_t iters = (n_in + stride - 1) / stride;
-  uint32_t* list = a.defer_list + (size_t)blockIdx.x * iters * SHADE_BLOCK; // this workgroup's region
+  uint4* list = a.defer_list + (size_t)blockIdx.x * iters * SHADE_BLOCK; // this workgroup's region
   if (threadIdx.x == 0) list_tail = 0u;
   __syncthreads();
   Counters ctr = {0, 0, 0, 0, 0, 0, 0};
@@ -552,13 +556,15 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MISS_WAVES) void shade_miss_kern
   const int lane = threadIdx.x & 63;
   for (uint32_t k = 0, i = blockIdx.x * SHADE_BLOCK + threadIdx.x; k < iters; k++, i += stride) {
     ShadeOut o;
-    const bool deferred = shade_path<INTEG, FULLCTR, 1, STAGE>(a, i, i < n_in, ctr, n_samples, o);
+    ShadeIn in;
+    shade_load<INTEG, 1, STAGE>(a, i, i < n_in, in);
+    const bool deferred = shade_body<INTEG, FULLCTR, 1, STAGE>(a, i, i < n_in, in, ctr, n_samples, o);
     const unsigned long long m = ballot(deferred);
     if (m) {
       uint32_t base = 0;
       if (lane == 0) base = atomicAdd(&list_tail, (uint32_t)__popcll(m)); // LDS
       base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-      if (deferred) list[base + lane_rank(m)] = i;
+      if (deferred) list[base + lane_rank(m)] = make_uint4(i, (uint32_t)in.h.x, (uint32_t)in.h.y, (uint32_t)in.sh.x);
     }
   }
   __syncthreads();
@@ -586,8 +592,13 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_hit_kernel(WfArgs a) {
   const uint32_t n_in = B0 ? a.n_slots : *a.n_in;
   const uint32_t stride = gridDim.x * SHADE_BLOCK;
   const uint32_t iters = (n_in + stride - 1) / stride;
-  const uint32_t* list = a.defer_list + (size_t)blockIdx.x * iters * SHADE_BLOCK;
+  const uint4* list = a.defer_list + (size_t)blockIdx.x * iters * SHADE_BLOCK;
   const uint32_t cnt = a.defer_count[blockIdx.x];
+  auto shade_entry = [&](const uint4 e, Counters& c, uint32_t& ns, ShadeOut& o) {
+    ShadeIn in;
+    shade_load<INTEG, 2, STAGE>(a, e.x, true, in, &e);
+    shade_body<INTEG, FULLCTR, 2, STAGE>(a, e.x, true, in, c, ns, o);
+  };
   Counters ctr = {0, 0, 0, 0, 0, 0, 0};
   uint32_t n_samples = 0;
   if (!MIS) {
@@ -600,7 +611,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_hit_kernel(WfArgs a) {
     const uint32_t base = alloc_lds[0];
     for (uint32_t j = threadIdx.x; j < cnt; j += SHADE_BLOCK) {
       ShadeOut o;
-      shade_path<INTEG, FULLCTR, 2, STAGE>(a, list[j], true, ctr, n_samples, o);
+      shade_entry(list[j], ctr, n_samples, o);
       if (o.emit) shade_store<MIS, FORM>(a, o, base + j);
       else if (a.bounce < a.p.max_bounce) // (a path that was pending and turned out to leave the scene: no ray in its slot)
         a.rq_out.d[base + j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -610,7 +621,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_hit_kernel(WfArgs a) {
       const uint32_t j = j0 + threadIdx.x;
       ShadeOut o;
       o.emit = false;
-      if (j < cnt) shade_path<INTEG, FULLCTR, 2, STAGE>(a, list[j], true, ctr, n_samples, o);
+      if (j < cnt) shade_entry(list[j], ctr, n_samples, o);
       shade_emit<MIS, FORM>(a, o, alloc_lds);
     }
   }
