@@ -68,7 +68,6 @@ struct Tuning {
   int leaf_threshold = 24; // lanes waiting at a leaf that trigger the triangle phase
   int pool_div = 1;        // ray-index pool = clamp(n_rays / (n_waves * pool_div), 8, pool_max)
   int pool_max = 128;      // rays per dynamic reservation (two 8x8 sub-blocks; affordable since the reservations spread over 8 counters)
-  int dir_lds = 1;         // bounce stages: ray directions in LDS columns instead of VGPRs where the LDS has room (8 -> 5 spilled registers)
   int trace_wps_rel = 7;   // waves per SIMD of the primary stage's launch (traceq4_kernel<.., true>; 0: trace_wps).  That variant
                            // needs 79 VGPRs; at 72 it spills 7 and is still 1.5 % faster (seven waves hide more latency)
   int trace_wps = 6;       // traceq_kernel register budget: waves per SIMD (4, 5, 6 or 8); 6 = 80 VGPRs (8 B of
@@ -116,7 +115,6 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"pool_max", &Tuning::pool_max, 8, 4096},
                               {"trace_wps", &Tuning::trace_wps, 1, 8},
                               {"trace_wps_rel", &Tuning::trace_wps_rel, 0, 8},
-                              {"dir_lds", &Tuning::dir_lds, 0, 1},
                               {"lds_nodes", &Tuning::lds_nodes, 0, 1 << 24},
                               {"steal", &Tuning::steal, 0, 1},
                               {"rel_boxes", &Tuning::rel_boxes, 0, 1},
@@ -401,8 +399,8 @@ void launch_traceq_cfg(EzrtScene* s, const TraceCfg& c, const TraceQArgs& q, boo
 // waves per SIMD of a traceq4 launch: the primary stage's variant may run one more (trace_wps_rel), but only while
 // that still leaves room for a useful top of the tree in LDS (deep trees need the space for stack rows: C5 and C3
 // would stage ONE record at 7 workgroups per CU and lose 3 %)
-int records_staged4(const EzrtScene* s, bool dir_in_lds, int wps) {
-  const size_t lds_fixed = (size_t)s->stack_need4 * BLOCK * sizeof(int) + BLOCK * sizeof(int) + (dir_in_lds ? 3 * BLOCK * sizeof(float) : 0);
+int records_staged4(const EzrtScene* s, int wps) {
+  const size_t lds_fixed = (size_t)s->stack_need4 * BLOCK * sizeof(int) + BLOCK * sizeof(int);
   size_t budget = (size_t)(158 * 1024) / (size_t)(wps > 0 ? wps : 1);
   if (budget > 64 * 1024) budget = 64 * 1024;
   budget -= budget / 16;
@@ -410,19 +408,16 @@ int records_staged4(const EzrtScene* s, bool dir_in_lds, int wps) {
 }
 int wps4(const EzrtScene* s, bool rel) {
   const int w = s->tune.trace_wps_rel;
-  if (rel && w > 0 && (w <= s->tune.trace_wps || records_staged4(s, false, w) >= std::min(24, s->n_inner4))) return w;
+  if (rel && w > 0 && (w <= s->tune.trace_wps || records_staged4(s, w) >= std::min(24, s->n_inner4))) return w;
   return s->tune.trace_wps;
 }
-// the bounce stages' variant with the ray directions in LDS: 3 KB per workgroup that deep trees need for stack rows
-bool dir_in_lds4(const EzrtScene* s, bool rel) {
-  return !rel && s->tune.dir_lds && records_staged4(s, true, s->tune.trace_wps) >= std::min(24, s->n_inner4);
-}
+// rel: the launch traverses boxes translated by a common origin (traceq4_kernel<.., true>)
 TraceCfg trace_cfg4(const EzrtScene* s, bool rel) {
   TraceCfg c;
   Tuning tu = s->tune;
   tu.trace_wps = wps4(s, rel);
   c.lds = (size_t)s->stack_need4 * BLOCK * sizeof(int);
-  const size_t lds_fixed = c.lds + BLOCK * sizeof(int) + (dir_in_lds4(s, rel) ? 3 * BLOCK * sizeof(float) : 0);
+  const size_t lds_fixed = c.lds + BLOCK * sizeof(int);
   int blocks_per_cu = tu.trace_wps > 0 ? tu.trace_wps : 5;
   if ((size_t)blocks_per_cu * lds_fixed > 158 * 1024) blocks_per_cu = (int)((158 * 1024) / lds_fixed);
   if (blocks_per_cu < 1) blocks_per_cu = 1;
@@ -444,21 +439,21 @@ bool use_wide4(const EzrtScene* s) {
   return s->tune.wide4 && s->n_inner4 > 0 && s->instr == 0 &&
          ((size_t)s->stack_need4 + 1) * BLOCK * sizeof(int) <= 60 * 1024; // stack rows + lane table
 }
-template <bool REL, bool DLDS, bool LOG>
+template <bool REL, bool LOG>
 void launch_traceq4_v(EzrtScene* s, const TraceCfg& c, const TraceQ4Args& q, hipStream_t st) {
   const int trace_wps = wps4(s, REL);
   const dim3 grid(c.grid_full), block(BLOCK);
-  if (trace_wps == 8) hipLaunchKernelGGL((traceq4_kernel<8, REL, DLDS, LOG>), grid, block, c.lds_t, st, q);
-  else if (trace_wps == 7) hipLaunchKernelGGL((traceq4_kernel<7, REL, DLDS, LOG>), grid, block, c.lds_t, st, q);
-  else if (trace_wps == 6) hipLaunchKernelGGL((traceq4_kernel<6, REL, DLDS, LOG>), grid, block, c.lds_t, st, q);
-  else if (trace_wps == 4) hipLaunchKernelGGL((traceq4_kernel<4, REL, DLDS, LOG>), grid, block, c.lds_t, st, q);
-  else hipLaunchKernelGGL((traceq4_kernel<5, REL, DLDS, LOG>), grid, block, c.lds_t, st, q);
+  if (trace_wps == 8) hipLaunchKernelGGL((traceq4_kernel<8, REL, LOG>), grid, block, c.lds_t, st, q);
+  else if (trace_wps == 7) hipLaunchKernelGGL((traceq4_kernel<7, REL, LOG>), grid, block, c.lds_t, st, q);
+  else if (trace_wps == 6) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG>), grid, block, c.lds_t, st, q);
+  else if (trace_wps == 4) hipLaunchKernelGGL((traceq4_kernel<4, REL, LOG>), grid, block, c.lds_t, st, q);
+  else hipLaunchKernelGGL((traceq4_kernel<5, REL, LOG>), grid, block, c.lds_t, st, q);
   s->n_trace_launches++;
 }
-template <bool REL, bool DLDS>
+template <bool REL>
 void launch_traceq4_rel(EzrtScene* s, const TraceCfg& c, const TraceQ4Args& q, hipStream_t st) {
-  if (q.q.wave_log) launch_traceq4_v<REL, DLDS, true>(s, c, q, st); // (debug_stages=2)
-  else launch_traceq4_v<REL, DLDS, false>(s, c, q, st);
+  if (q.q.wave_log) launch_traceq4_v<REL, true>(s, c, q, st); // (debug_stages=2)
+  else launch_traceq4_v<REL, false>(s, c, q, st);
 }
 // t: the stage's queue arguments as for the binary kernel (knobs already filled); rel: 4-wide records translated by
 // t.origin (or NULL)
@@ -472,9 +467,8 @@ void launch_traceq4_cfg(EzrtScene* s, const TraceCfg& c4, const TraceQArgs& t, c
   A.inner4_rel = rel;
   A.root4 = s->root4;
   A.lds_nodes4 = c4.lds_nodes;
-  if (rel) launch_traceq4_rel<true, false>(s, c4, A, st);
-  else if (dir_in_lds4(s, false)) launch_traceq4_rel<false, true>(s, c4, A, st);
-  else launch_traceq4_rel<false, false>(s, c4, A, st);
+  if (rel) launch_traceq4_rel<true>(s, c4, A, st);
+  else launch_traceq4_rel<false>(s, c4, A, st);
 }
 
 // schedule fields of a traceq launch that come from the knobs (clamped: ADVICE r1)

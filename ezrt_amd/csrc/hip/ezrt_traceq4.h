@@ -80,31 +80,21 @@ __global__ void inner4_rel_kernel(const float4* in, int n, float sx, float sy, f
   o[7] = r[7];
 }
 
-// DLDS (only without REL): ray directions in LDS columns instead of VGPRs (see lds_dir below); chosen by the host when
-// the tree's stack rows leave room for them next to a useful number of staged records
 // LOG: the per-wave diagnostics of debug_stages=2 (a.wave_log).  A template parameter, not a run-time test: the
 // counters and time stamps are loop-carried values, and even never-executed they cost the production kernel registers
 // (one 64-bit time stamp turned 4 spills into 7: -2 %).
-template <int WPS, bool REL, bool DLDS = false, bool LOG = false>
+template <int WPS, bool REL, bool LOG = false>
 __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
-  static_assert(!(REL && DLDS), "the primary stage's variant keeps its directions in registers");
   extern __shared__ __attribute__((aligned(16))) int lds_stack[];
   const TraceQArgs& a = A.q;
-  // LDS layout: [lane table: BLOCK ints][DLDS: direction columns, 3 x BLOCK floats][stack rows][staged records] -- the
-  // per-lane columns first, at compile-time offsets from ONE per-lane address (fewer loop-invariant VGPRs)
-  int* stack = lds_stack + BLOCK + (DLDS ? 3 * BLOCK : 0) + threadIdx.x;
+  // LDS layout: [lane table: BLOCK ints][stack rows][staged records]
+  int* stack = lds_stack + BLOCK + threadIdx.x;
   const TraceScene& sc = a.sc;
   const uint32_t n_rays = (*a.n_paths) * a.rays_per_path;
   const int lane = threadIdx.x & 63;
   if (n_rays == 0) return;
   int* wsrc = lds_stack + (threadIdx.x >> 6) * 64;
-  // DLDS: the ray direction lives in LDS (three BLOCK-float columns after the lane table), not in VGPRs: it is only
-  // read in the leaf and steal phases -- by OTHER lanes, through what used to be shuffles -- and the three registers
-  // are the difference between spilling loop invariants and not (80-VGPR budget)
-  float* lds_dir = reinterpret_cast<float*>(lds_stack + BLOCK);
-  float* my_dir = lds_dir + threadIdx.x;
-  float* wave_dir = lds_dir + (threadIdx.x & ~63);
-  float4* lds_nodes = reinterpret_cast<float4*>(lds_stack + BLOCK + (DLDS ? 3 * BLOCK : 0) + a.stack_entries * BLOCK);
+  float4* lds_nodes = reinterpret_cast<float4*>(lds_stack + BLOCK + a.stack_entries * BLOCK);
   const float4* inner = REL ? A.inner4_rel : A.inner4;
   for (int k = threadIdx.x; k < A.lds_nodes4 * 7; k += BLOCK) lds_nodes[k] = inner[(k / 7) * N4_FLOAT4 + (k % 7)];
   __syncthreads();
@@ -194,11 +184,6 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
           // it, no prefetched origin, none of its shuffles in the leaf and steal phases (7 VGPRs less at a budget of 80)
           S = REL ? mk(a.origin[0], a.origin[1], a.origin[2]) : mk(nx_o.x, nx_o.y, nx_o.z);
           d = mk(nx_d.x, nx_d.y, nx_d.z);
-          if (DLDS) {
-            my_dir[0] = d.x;
-            my_dir[BLOCK] = d.y;
-            my_dir[2 * BLOCK] = d.z;
-          }
           inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
           best_t = INF;
           best_tri = -1;
@@ -284,18 +269,12 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
           const uint32_t vslot = (uint32_t)__shfl((int)slot, src, 64);
           const float vsx = REL ? a.origin[0] : __shfl(S.x, src, 64), vsy = REL ? a.origin[1] : __shfl(S.y, src, 64),
                       vsz = REL ? a.origin[2] : __shfl(S.z, src, 64);
-          const float vdx = !DLDS ? __shfl(d.x, src, 64) : wave_dir[src], vdy = !DLDS ? __shfl(d.y, src, 64) : wave_dir[BLOCK + src],
-                      vdz = !DLDS ? __shfl(d.z, src, 64) : wave_dir[2 * BLOCK + src];
+          const float vdx = __shfl(d.x, src, 64), vdy = __shfl(d.y, src, 64), vdz = __shfl(d.z, src, 64);
           if (thief) {
             shared = true;
             slot = vslot;
             S = mk(vsx, vsy, vsz);
             d = mk(vdx, vdy, vdz);
-            if (DLDS) {
-              my_dir[0] = vdx;
-              my_dir[BLOCK] = vdy;
-              my_dir[2 * BLOCK] = vdz;
-            }
             inv = mk(1.0f / vdx, 1.0f / vdy, 1.0f / vdz);
             best_t = INF;
             best_tri = -1;
@@ -452,8 +431,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
           const int src = helper ? wsrc[grp] : lane;
           const f3 cS = REL ? mk(a.origin[0], a.origin[1], a.origin[2])
                             : mk(__shfl(S.x, src, 64), __shfl(S.y, src, 64), __shfl(S.z, src, 64));
-          const f3 cd = !DLDS ? mk(__shfl(d.x, src, 64), __shfl(d.y, src, 64), __shfl(d.z, src, 64))
-                              : mk(wave_dir[src], wave_dir[BLOCK + src], wave_dir[2 * BLOCK + src]);
+          const f3 cd = mk(__shfl(d.x, src, 64), __shfl(d.y, src, 64), __shfl(d.z, src, 64));
           const uint32_t lref = (uint32_t)__shfl((int)ref, src, 64);
           unsigned long long key = ~0ull;
           if (helper) {
@@ -478,9 +456,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
           const int n = (int)((ref >> 24) & 0x7fu) + 1;
           for (int i = first; i < first + n; i++) {
             float t;
-            if (hit_triangle_t(sc.tri_geom + (size_t)i * 3, REL ? mk(a.origin[0], a.origin[1], a.origin[2]) : S,
-                               !DLDS ? d : mk(my_dir[0], my_dir[BLOCK], my_dir[2 * BLOCK]), t))
-              take(t, i);
+            if (hit_triangle_t(sc.tri_geom + (size_t)i * 3, REL ? mk(a.origin[0], a.origin[1], a.origin[2]) : S, d, t)) take(t, i);
           }
         }
         if (at_leaf) {
