@@ -327,7 +327,12 @@ int ensure_events(EzrtScene* s) {
   }
   for (Pipe& q : s->pipe) {
     HIP_TRY(hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&q.side, hipStreamNonBlocking));
+    {
+      // the redo launches are a handful of rays on the critical path of the stage's second shading pass: highest priority
+      int prio_lo = 0, prio_hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+      HIP_TRY(hipStreamCreateWithPriority(&q.side, hipStreamNonBlocking, prio_hi));
+    }
     HIP_TRY(hipEventCreateWithFlags(&q.ev_main, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&q.ev_redo, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&q.ev_done, hipEventDisableTiming));
