@@ -529,6 +529,33 @@ EZD float hdr_pdf(const DevScene& sc, f3 L, Counters& ctr) {
   return pdf * p_convert;
 }
 
+// hdrColor(L) and hdrPdf(L) of the SAME direction (P5/fsh:829-830, 873-874): both start with
+// toSphericalCoord(normalize(L)) -- a software atan2 and asin, ~170 instructions -- evaluated once here; the same
+// operations on the same operands, so the same bits as the two separate calls (the compiler does not merge them).
+template <bool FULLCTR>
+EZD void hdr_color_pdf(const DevScene& sc, f3 L, float env_clamp, Counters& ctr, f3& color, float& pdf_light) {
+  if (FULLCTR) {
+    ctr.envmap++;
+    ctr.envcache++;
+  }
+  float u, v;
+  to_spherical(normalize(L), u, v);
+  if (!sc.hdr) {
+    color = mk(0, 0, 0);
+  } else {
+    f3 c = sc.hdr_rgbe ? tex_fetch_rgbe(sc.hdr_rgbe, sc.env_w, sc.env_h, sc.env_filter, u, v)
+                       : tex_fetch(sc.hdr, sc.env_w, sc.env_h, sc.env_filter, u, v);
+    if (env_clamp > 0.0f) c = mk(ez_min(c.x, env_clamp), ez_min(c.y, env_clamp), ez_min(c.z, env_clamp));
+    color = c;
+  }
+  float pdf = tex_fetch(sc.cache, sc.env_w, sc.env_h, sc.env_filter, u, v).z;
+  float theta = PI * (0.5f - v);
+  float sin_theta = ez_max(ez_sin(theta), 1e-10f);
+  int res = sc.env_w;
+  float p_convert = (float)(res * res / 2) / (2.0f * PI * PI * sin_theta);
+  pdf_light = pdf * p_convert;
+}
+
 // ---------------------------------------------------------------------------
 // Disney principled BRDF: P5/fsh:400-549 (isotropic), P4/fsh:375-473 (anisotropic)
 EZD float schlick(float u) {
@@ -757,6 +784,70 @@ EZD float brdf_pdf_aniso(f3 V, f3 N, f3 L, f3 X, f3 Y, const Mat& m) {
   float p_clearcoat = r_clearcoat / r_sum;
   float pdf = p_diffuse * pdf_diffuse + p_specular * pdf_specular + p_clearcoat * pdf_clearcoat;
   return ez_max(1e-10f, pdf);
+}
+
+// BRDF_Evaluate(V, N, L) and BRDF_Pdf(V, N, L) of the SAME direction (P5/fsh:832-833, 858-859): both start with
+// H = normalize(L + V), N.H, L.H and both evaluate GTR2 / GTR1 of that half vector -- once here.  The same operations
+// on the same operands as brdf_evaluate<ANISO> followed by brdf_pdf (ANISO: brdf_pdf_aniso), hence the same bits; the
+// compiler does not merge the two calls (a normalisation, two divisions and the GTR terms per pair).
+template <bool ANISO>
+EZD void brdf_evaluate_pdf(f3 V, f3 N, f3 L, f3 X, f3 Y, const Mat& m, f3& f_r, float& pdf_out) {
+  float NdotL = dot(N, L), NdotV = dot(N, V);
+  if (NdotL < 0.0f || NdotV < 0.0f) {
+    f_r = mk(0, 0, 0);
+    pdf_out = 0.0f;
+    return;
+  }
+  f3 H = normalize(L + V);
+  float NdotH = dot(N, H), LdotH = dot(L, H);
+  const f3 Cdlin = m.baseColor, one = mk(1, 1, 1), Cspec0 = m.Cspec0, Csheen = m.Csheen;
+
+  float Fd90 = 0.5f + 2.0f * LdotH * LdotH * m.roughness;
+  float FL = schlick(NdotL), FV = schlick(NdotV);
+  float Fd = ez_mix(1.0f, Fd90, FL) * ez_mix(1.0f, Fd90, FV);
+
+  float Fss90 = LdotH * LdotH * m.roughness;
+  float Fss = ez_mix(1.0f, Fss90, FL) * ez_mix(1.0f, Fss90, FV);
+  float ss = 1.25f * (Fss * (1.0f / (NdotL + NdotV) - 0.5f) + 0.5f);
+
+  float Ds, Gs;
+  float FH = schlick(LdotH);
+  f3 Fs = mix3(Cspec0, one, FH);
+  if (!ANISO) {
+    Ds = gtr2(NdotH, m.alpha_gtr2);
+    Gs = smith_ggx(NdotL, m.roughness);
+    Gs *= smith_ggx(NdotV, m.roughness);
+  } else {
+    float aspect = __builtin_sqrtf(1.0f - m.anisotropic * 0.9f);
+    float ax = ez_max(0.001f, sqr(m.roughness) / aspect);
+    float ay = ez_max(0.001f, sqr(m.roughness) * aspect);
+    Ds = gtr2_aniso(NdotH, dot(H, X), dot(H, Y), ax, ay);
+    Gs = smith_ggx_aniso(NdotL, dot(L, X), dot(L, Y), ax, ay);
+    Gs *= smith_ggx_aniso(NdotV, dot(V, X), dot(V, Y), ax, ay);
+  }
+  float Dr = gtr1_m(NdotH, m);
+  float Fr = ez_mix(0.04f, 1.0f, FH);
+  float Gr = smith_ggx(NdotL, 0.25f) * smith_ggx(NdotV, 0.25f);
+
+  f3 Fsheen = Csheen * (FH * m.sheen);
+  f3 diffuse = Cdlin * ((1.0f / PI) * ez_mix(Fd, ss, m.subsurface)) + Fsheen;
+  f3 specular = (Fs * Gs) * Ds;
+  float cc = 0.25f * Gr * Fr * Dr * m.clearcoat;
+  f_r = (diffuse * (1.0f - m.metallic) + specular) + mk(cc, cc, cc);
+
+  // BRDF_Pdf: P5/fsh:729-751 on the same H, Ds, Dr
+  float pdf_diffuse = NdotL / PI;
+  float pdf_specular = Ds * NdotH / (4.0f * LdotH);
+  float pdf_clearcoat = Dr * NdotH / (4.0f * LdotH);
+  float r_diffuse = 1.0f - m.metallic;
+  float r_specular = 1.0f;
+  float r_clearcoat = 0.25f * m.clearcoat;
+  float r_sum = r_diffuse + r_specular + r_clearcoat;
+  float p_diffuse = r_diffuse / r_sum;
+  float p_specular = r_specular / r_sum;
+  float p_clearcoat = r_clearcoat / r_sum;
+  float pdf = p_diffuse * pdf_diffuse + p_specular * pdf_specular + p_clearcoat * pdf_clearcoat;
+  pdf_out = ez_max(1e-10f, pdf);
 }
 
 } // namespace ezd

@@ -153,10 +153,12 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
             hit_bvh<FULLCTR, BLOCK>(sc, hit.P, Lh, stack, st, stt, ctr);
             plog<PATHLOG>(a, pix, 1 + 2 * bounce, st, stt);
             if (st < 0) {
-              f3 color = hdr_color<FULLCTR>(sc, Lh, p.env_clamp, ctr);
-              float pdf_light = hdr_pdf<FULLCTR>(sc, Lh, ctr);
-              f3 f_r = brdf_evaluate<ANISO_IS>(V, N, Lh, X, Y, hit.m);
-              float pdf_brdf = ANISO_IS ? brdf_pdf_aniso(V, N, Lh, X, Y, hit.m) : brdf_pdf(V, N, Lh, hit.m);
+              f3 color;
+              float pdf_light;
+              hdr_color_pdf<FULLCTR>(sc, Lh, p.env_clamp, ctr, color, pdf_light);
+              f3 f_r;
+              float pdf_brdf;
+              brdf_evaluate_pdf<ANISO_IS>(V, N, Lh, X, Y, hit.m, f_r, pdf_brdf);
               float w = mis_mix_weight(pdf_light, pdf_brdf);
               Lo = Lo + (((history * w) * color) * f_r) * dot(N, Lh) / pdf_light;
             }
@@ -197,14 +199,15 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
         hit_bvh<FULLCTR, BLOCK>(sc, hit.P, L, stack, nt, ntt, ctr);
         plog<PATHLOG>(a, pix, 2 + 2 * bounce, nt, ntt);
         if (MIS) {
-          f_r = brdf_evaluate<ANISO_IS>(V, N, L, X, Y, hit.m);
-          pdf = ANISO_IS ? brdf_pdf_aniso(V, N, L, X, Y, hit.m) : brdf_pdf(V, N, L, hit.m);
+          brdf_evaluate_pdf<ANISO_IS>(V, N, L, X, Y, hit.m, f_r, pdf);
           if (pdf <= 0.0f) break;
         }
         if (nt < 0) {
-          f3 sky = hdr_color<FULLCTR>(sc, L, p.env_clamp, ctr);
+          f3 sky;
+          float pdf_light = 0.0f;
+          if (MIS) hdr_color_pdf<FULLCTR>(sc, L, p.env_clamp, ctr, sky, pdf_light);
+          else sky = hdr_color<FULLCTR>(sc, L, p.env_clamp, ctr);
           if (MIS) {
-            float pdf_light = hdr_pdf<FULLCTR>(sc, L, ctr);
             float w = mis_mix_weight(pdf, pdf_light);
             Lo = Lo + (((history * w) * sky) * f_r) * cosine / pdf;
           } else {

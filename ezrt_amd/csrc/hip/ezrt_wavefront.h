@@ -377,9 +377,11 @@ EZD bool shade_body(const WfArgs& a, const uint32_t i, bool live, const ShadeIn&
       done = true;
     } else {
       if (h.x < 0) {
-        f3 sky = hdr_color<FULLCTR>(sc, rd, p.env_clamp, ctr);
+        f3 sky;
+        float pdf_light = 0.0f;
+        if (MIS) hdr_color_pdf<FULLCTR>(sc, rd, p.env_clamp, ctr, sky, pdf_light);
+        else sky = hdr_color<FULLCTR>(sc, rd, p.env_clamp, ctr);
         if (MIS) {
-          float pdf_light = hdr_pdf<FULLCTR>(sc, rd, ctr);
           float w = mis_mix_weight(pdf, pdf_light);
           Lo = Lo + (((history * w) * sky) * f_r) * cosine / pdf;
         } else {
@@ -421,10 +423,12 @@ EZD bool shade_body(const WfArgs& a, const uint32_t i, bool live, const ShadeIn&
         shadowL = Lh;
         // contribution if unoccluded, evaluated eagerly (pure functions of the path state)
         Counters dummy = {0, 0, 0, 0, 0, 0, 0};
-        f3 color = hdr_color<false>(sc, Lh, p.env_clamp, dummy);
-        float pdf_light = hdr_pdf<false>(sc, Lh, dummy);
-        f3 fr = brdf_evaluate<ANISO_IS>(V, N, Lh, X, Y, hit.m);
-        float pdf_brdf = ANISO_IS ? brdf_pdf_aniso(V, N, Lh, X, Y, hit.m) : brdf_pdf(V, N, Lh, hit.m);
+        f3 color;
+        float pdf_light;
+        hdr_color_pdf<false>(sc, Lh, p.env_clamp, dummy, color, pdf_light);
+        f3 fr;
+        float pdf_brdf;
+        brdf_evaluate_pdf<ANISO_IS>(V, N, Lh, X, Y, hit.m, fr, pdf_brdf);
         float w = mis_mix_weight(pdf_light, pdf_brdf);
         shadowC = (((history * w) * color) * fr) * dot(N, Lh) / pdf_light;
       }
@@ -449,8 +453,7 @@ EZD bool shade_body(const WfArgs& a, const uint32_t i, bool live, const ShadeIn&
         shoot = false;
         flags |= FLAG_TERMINATE;
       } else {
-        f_r = brdf_evaluate<ANISO_IS>(V, N, rayL, X, Y, hit.m);
-        pdf = ANISO_IS ? brdf_pdf_aniso(V, N, rayL, X, Y, hit.m) : brdf_pdf(V, N, rayL, hit.m);
+        brdf_evaluate_pdf<ANISO_IS>(V, N, rayL, X, Y, hit.m, f_r, pdf);
         if (pdf <= 0.0f) flags |= FLAG_PDF_DEAD;
       }
     } else {
