@@ -18,6 +18,7 @@
 #include "ezrt_wavefront.h"
 #include "ezrt_tracepk.h"
 #include "ezrt_traceq4.h"
+#include "ezrt_streams.h"
 
 using namespace ezd;
 
@@ -164,6 +165,7 @@ struct Pipe {
   DevBuf<float4> inner4_rel;    // 4-wide records translated by -eye
   DevBuf<uint4> defer_list;     // split shading: paths with a surface interaction, per workgroup
   DevBuf<uint32_t> defer_count;
+  int stream_device = 0;         // device `stream` and `side` belong to (they return to its pool)
   hipStream_t side = nullptr;    // redo launches that overlap the first shading pass
   hipEvent_t ev_main = nullptr;  // a stage's main trace launch is enqueued / done
   hipEvent_t ev_redo = nullptr;  // ... its redo launch is done
@@ -326,13 +328,10 @@ int ensure_events(EzrtScene* s) {
     HIP_TRY(hipEventCreate(&s->ev_trace[i][1]));
   }
   for (Pipe& q : s->pipe) {
-    HIP_TRY(hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking));
-    {
-      // the redo launches are a handful of rays on the critical path of the stage's second shading pass: highest priority
-      int prio_lo = 0, prio_hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-      HIP_TRY(hipStreamCreateWithPriority(&q.side, hipStreamNonBlocking, prio_hi));
-    }
+    // (from the process-wide pool: ezrt_streams.h says why the library never destroys a stream)
+    HIP_TRY(ezh::stream_acquire(false, &q.stream, &q.stream_device));
+    // the redo launches are a handful of rays on the critical path of the stage's second shading pass: highest priority
+    HIP_TRY(ezh::stream_acquire(true, &q.side, &q.stream_device));
     HIP_TRY(hipEventCreateWithFlags(&q.ev_main, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&q.ev_redo, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&q.ev_done, hipEventDisableTiming));
@@ -1240,8 +1239,8 @@ void ezrt_scene_destroy(EzrtScene* s) {
     (void)hipEventDestroy(s->ev_begin);
     (void)hipEventDestroy(s->ev_end);
     for (Pipe& q : s->pipe) {
-      if (q.stream) (void)hipStreamDestroy(q.stream);
-      if (q.side) (void)hipStreamDestroy(q.side);
+      ezh::stream_park(q.stream, false, q.stream_device);
+      ezh::stream_park(q.side, true, q.stream_device);
       if (q.ev_main) (void)hipEventDestroy(q.ev_main);
       if (q.ev_redo) (void)hipEventDestroy(q.ev_redo);
       if (q.ev_done) (void)hipEventDestroy(q.ev_done);

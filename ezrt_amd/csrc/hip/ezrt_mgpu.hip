@@ -17,6 +17,7 @@
 
 #include "ezrt_mgpu.h"
 #include "ezrt_tiles.h"
+#include "ezrt_streams.h"
 
 extern "C" int ezrt_fail_msg(int code, const char* msg); // ezrt_hip.hip: sets ezrt_last_error()
 
@@ -180,7 +181,8 @@ int ezrt_mgpu_create(const float* tri, int n_tri, const float* nodes, int n_node
     if (hipSetDevice(q.dev) != hipSuccess) return bail(mfail(EZRT_ERR_DEVICE, "hipSetDevice failed"));
     int rc = ezrt_scene_create(tri, n_tri, nodes, n_nodes, &q.sc); // allocates on the current device
     if (rc) return bail(rc);
-    if (hipStreamCreateWithFlags(&q.st, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&q.e0) != hipSuccess ||
+    int st_dev = 0; // (= q.dev; the library's streams come from and return to its pool: ezrt_streams.h)
+    if (ezh::stream_acquire(false, &q.st, &st_dev) != hipSuccess || hipEventCreate(&q.e0) != hipSuccess ||
         hipEventCreate(&q.e1) != hipSuccess || hipEventCreateWithFlags(&q.e_ready, hipEventDisableTiming) != hipSuccess)
       return bail(mfail(EZRT_ERR_DEVICE, "stream/event creation failed"));
   }
@@ -224,7 +226,7 @@ void ezrt_mgpu_destroy(EzrtMgpu* m) {
     if (q.e0) (void)hipEventDestroy(q.e0);
     if (q.e1) (void)hipEventDestroy(q.e1);
     if (q.e_ready) (void)hipEventDestroy(q.e_ready);
-    if (q.st) (void)hipStreamDestroy(q.st);
+    ezh::stream_park(q.st, false, q.dev);
   }
   if (!m->r.empty()) (void)hipSetDevice(m->r[0].dev);
   if (m->recv) (void)hipFree(m->recv);

@@ -1,0 +1,60 @@
+"""Scenes come and go in one process (the progressive renderer reloads, a host loads the next model): a scene created
+after another was destroyed must render the same bits at the same speed.  The library parks its streams instead of
+destroying them (ezrt_amd/csrc/hip/ezrt_streams.h): with hipStreamDestroy in ezrt_scene_destroy the second scene's
+cross-stream event waits were slow and its frames took 15-35 % longer."""
+import statistics
+import time
+
+import numpy as np
+import pytest
+import torch  # before the fixture loads libezrt_hip.so: both must resolve the same HIP runtime
+
+
+def _frame_ms(sc, p, acc, st, torch, reps=9):
+    sc.render_device(p, acc.data_ptr(), st)
+    torch.cuda.synchronize()
+    ms = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        sc.render_device(p, acc.data_ptr(), st)
+        torch.cuda.synchronize()
+        ms.append((time.perf_counter() - t0) * 1e3)
+    return statistics.median(ms)
+
+
+@pytest.mark.gpu
+def test_scene_after_a_destroyed_scene_renders_the_same_bits_at_the_same_speed(hip):
+    from ezrt_amd import scene as S, scenes, trace
+    bs = scenes.bunny_scene(subdiv=1, hdr="shipped")
+    eye, cam = S.camera(0, 0, 4.0)
+    p = trace.make_params(512, 512, eye, cam, 50, 4, spp=16)
+    st = torch.cuda.current_stream().cuda_stream
+    frames, times = [], []
+    for _ in range(4):
+        sc = bs.upload(hip)
+        acc = torch.zeros((512, 512, 4), dtype=torch.float32, device="cuda")
+        times.append(_frame_ms(sc, p, acc, st, torch))
+        frames.append(acc.cpu().numpy())
+        sc.close()
+    for f in frames[1:]:
+        assert np.array_equal(f.view(np.uint32), frames[0].view(np.uint32))
+    assert max(times[1:]) < 1.12 * times[0] + 0.05, times
+
+
+@pytest.mark.gpu
+def test_two_scenes_alive_at_once_have_their_own_streams(hip):
+    """Two live scenes must not share the pooled streams (each takes its own pair); both render the single-scene bits."""
+    from ezrt_amd import scene as S, scenes, trace
+    bs = scenes.bunny_scene(subdiv=0, want_cache=True, hdr="shipped")
+    eye, cam = S.camera(30, 10, 4.0)
+    p = trace.make_params(128, 128, eye, cam, 51, 3, spp=4)
+    a, b = bs.upload(hip), bs.upload(hip)
+    fa, fb = a.render(p), b.render(p)
+    a.close()
+    c = bs.upload(hip)   # takes a's parked streams while b is alive
+    fc, fb2 = c.render(p), b.render(p)
+    b.close()
+    c.close()
+    assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32))
+    assert np.array_equal(fa.view(np.uint32), fc.view(np.uint32))
+    assert np.array_equal(fa.view(np.uint32), fb2.view(np.uint32))
