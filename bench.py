@@ -212,6 +212,7 @@ def main():
     # per-step GPU times (hipEvents on the launch stream; reading them synchronises, so this is a separate, untimed
     # pass of the same step): median of 7 -- (all kernels, the trace launches, number of trace launches)
     rays_timed = sc.counters()["rays"]
+    sc.set_option("launch_events", 1)   # (a timing-event pair around every trace launch: off in the timed loop above)
     for _ in range(7):
         sc.render_device(p, accum.data_ptr(), stream)
         step_ms.append(sc.last_render_ms())

@@ -97,6 +97,8 @@ struct Tuning {
                            // dependent traversal steps) runs on a side stream under the stage's first shading pass; the
                            // second pass waits for it (0: in line, before any shading)
   int debug_force_pending = 0; // test hook: every k-th ray slot takes the not-tame route (HIT_PENDING -> redo -> second pass)
+  int launch_events = 0;   // 1: a pair of timing events around every trace launch (ezrt_last_render_ms's second figure; each
+                           // record costs the stream ~5 us: -1.2 % on C2); 0: only the call's begin / end events
   int env_rgbe = 1;        // environment lookups through the 4-byte RGBE form of the map when it has an exact one (set_env)
   int audit_via_queue = 0; // 1: ezrt_query_hits and ezrt_render_paths run through the TIMED kernels (traceq_kernel with
                            // the template, LDS layout, stealing and redo launch of a render call + the streaming shading
@@ -129,6 +131,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"tail_stage", &Tuning::tail_stage, 0, 64},
                               {"debug_stages", &Tuning::debug_stages, 0, 2},
                               {"env_rgbe", &Tuning::env_rgbe, 0, 1},
+                              {"launch_events", &Tuning::launch_events, 0, 1},
                               {"redo_overlap", &Tuning::redo_overlap, 0, 1},
                               {"debug_force_pending", &Tuning::debug_force_pending, 0, 1 << 20},
                               {"audit_via_queue", &Tuning::audit_via_queue, 0, 2}};
@@ -560,10 +563,8 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
   // [0..63] paths per stage, [64..99] queue heads, [100..119] debug, [120,121] packet redo,
   // [128..] redo counts per stage, [192..] redo queue heads per stage
   constexpr size_t HEAD_SLOT = (size_t)TRACE_HEADS * TRACE_HEAD_STRIDE; // launch slots: stage b, redo 40 + b, packet redo 80
-  HIP_TRY(pp.qheads.ensure(81 * HEAD_SLOT));
-  HIP_TRY(hipMemsetAsync(pp.qheads.p, 0, 81 * HEAD_SLOT * sizeof(uint32_t), st));
+  HIP_TRY(pp.qheads.ensure(81 * HEAD_SLOT)); // (both zeroed by raygen_kernel: ChunkPrologue)
   HIP_TRY(pp.qcounts.ensure(320));
-  HIP_TRY(hipMemsetAsync(pp.qcounts.p, 0, 320 * sizeof(uint32_t), st));
   HIP_TRY(pp.defer_list.ensure(n_slots + (size_t)2048 * 1024)); // per-workgroup regions: iterations x SHADE_BLOCK each
   HIP_TRY(pp.defer_count.ensure(2048u * 1024u / SHADE_BLOCK));
   {
@@ -635,12 +636,24 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
                        p->eye[0], p->eye[1], p->eye[2], pp.inner_rel.p);
   }
   const TraceCfg cfg4_rel = wide ? trace_cfg4(s, true) : TraceCfg(), cfg4_abs = wide ? trace_cfg4(s, false) : TraceCfg();
+  ChunkPrologue pro;
+  pro.zero_a = pp.qheads.p;
+  pro.n_zero_a = (uint32_t)(81 * HEAD_SLOT);
+  pro.zero_b = pp.qcounts.p;
+  pro.n_zero_b = 320u;
+  pro.inner4 = nullptr;
+  pro.inner4_rel = nullptr;
+  pro.n_inner4 = 0;
+  pro.sx = p->eye[0];
+  pro.sy = p->eye[1];
+  pro.sz = p->eye[2];
   if (wide && s->tune.rel_boxes) {
     HIP_TRY(pp.inner4_rel.ensure((size_t)s->n_inner4 * N4_FLOAT4));
-    hipLaunchKernelGGL(inner4_rel_kernel, dim3((unsigned)((s->n_inner4 + 255) / 256)), dim3(256), 0, st, s->inner4.p, s->n_inner4,
-                       p->eye[0], p->eye[1], p->eye[2], pp.inner4_rel.p);
+    pro.inner4 = s->inner4.p;
+    pro.inner4_rel = pp.inner4_rel.p;
+    pro.n_inner4 = s->n_inner4;
   }
-  hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((n_slots + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, a);
+  hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((n_slots + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, a, pro);
   if (s->tune.debug_stages && wide)
     fprintf(stderr, "[ezrt] traceq4 launches: %d stack rows (binary tree depth %d); primary stage %d workgroups/CU, %zu B LDS, %d records staged; "
             "bounce stages %d workgroups/CU, %zu B LDS, %d records staged\n", s->stack_need4, s->depth, cfg4_rel.blocks_per_cu, cfg4_rel.lds_t,
@@ -708,7 +721,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     // launch is still to write -- traceq4_kernel marks those HIT_PENDING -- and only in plain timed runs
     const bool overlap_redo = wide && split_here && tu.redo_overlap && !full && !plog && !debug_stages && !(b == 0 && use_packet);
     hipEvent_t ev_between = nullptr;
-    int e = s->n_trace_events;
+    int e = tu.launch_events ? s->n_trace_events : MAX_TRACE_EVENTS;
     if (e < MAX_TRACE_EVENTS) HIP_TRY(hipEventRecord(s->ev_trace[e][0], st));
     if (b == 0 && !full && use_packet) {
       // primary rays: packet traversal (one wave = one 8x8 tile); rays with an exact distance tie and

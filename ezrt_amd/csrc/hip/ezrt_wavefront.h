@@ -20,6 +20,7 @@
 #pragma once
 #include "ezrt_kernels.h"
 #include "ezrt_traceq.h"
+#include "ezrt_traceq4.h"
 
 namespace ezd {
 
@@ -99,8 +100,9 @@ EZD uint32_t queue_to_sample(uint32_t qslot, const FastDiv& n_sub_div, uint32_t 
 
 // ---------------------------------------------------------------------------
 // raygen: P5/fsh:315-318, 920-925
-__global__ __launch_bounds__(BLOCK) void raygen_kernel(WfArgs a) {
+__global__ __launch_bounds__(BLOCK) void raygen_kernel(WfArgs a, ChunkPrologue g) {
   const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+  chunk_prologue(g, slot, gridDim.x * BLOCK);
   if (slot >= a.n_slots) return;
   if (slot == 0) *a.n_out = a.n_slots; // stage 0's path count, read by the first trace launch
   if (blockIdx.x == 0) // the chunk's Sobol table (read by the shading stages): sobol(d, grayCode(frame + 1)), 16 dims per frame

@@ -159,7 +159,9 @@ int ezrt_counters_reset(EzrtScene* s);
 
 /* Device time of the kernels of the last ezrt_render* call on this scene, in
  * milliseconds, measured with hipEvents on the launch stream; total and the
- * trace kernel alone.  Forces a sync on the events. */
+ * trace launches alone -- the latter only with ezrt_set_option(s, "launch_events", 1) set before the call (a pair of
+ * events around every trace launch; off by default, each record costs the stream a few microseconds), 0 otherwise.
+ * Forces a sync on the events. */
 int ezrt_last_render_ms(EzrtScene* s, float* total_ms, float* trace_kernel_ms, int* n_trace_launches);
 
 /* Scene statistics computed at create time: [0] nTri [1] nNodes [2] tree depth

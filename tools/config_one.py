@@ -22,5 +22,6 @@ for _ in range(3):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 3
 rays = sc.counters()["rays"] / 3
+sc.set_option("launch_events", 1); sc.render_device(p, acc.data_ptr(), st)   # (untimed: per-launch events on)
 ms = sc.last_render_ms()
 print("%s spp %d: %.2f ms/call  %.0f Mrays/s  trace launches %.2f ms of %.2f" % (name, spp, dt * 1e3, rays / dt / 1e6, ms[1], ms[0]))

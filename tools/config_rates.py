@@ -35,6 +35,8 @@ def run(name, built, cfg, spp, integrator=None, sobol_dims=8, build_s=None):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     rays = sc.counters()["rays"] / reps
+    sc.set_option("launch_events", 1)   # (untimed extra call with a timing-event pair around every trace launch)
+    sc.render_device(p, acc.data_ptr(), st)
     ms = sc.last_render_ms()
     st_ = sc.stats()
     r = {"config": name, "triangles": int(built.tri.shape[0]), "nodes": int(built.nodes.shape[0]), "depth": int(st_["depth"]),

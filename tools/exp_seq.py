@@ -28,6 +28,7 @@ for name in sys.argv[1:]:
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
     rays = sc.counters()["rays"] / 3
+    sc.set_option("launch_events", 1); sc.render_device(p, acc.data_ptr(), st)
     ms = sc.last_render_ms()
     print("%s: %.2f ms/call  %.0f Mrays/s  trace %.2f of %.2f  free %.1f GB" % (name, dt * 1e3, rays / dt / 1e6, ms[1], ms[0], torch.cuda.mem_get_info()[0] / 1e9))
     if hold: keep.append(sc)
