@@ -97,6 +97,10 @@ struct Tuning {
                            // dependent traversal steps) runs on a side stream under the stage's first shading pass; the
                            // second pass waits for it (0: in line, before any shading)
   int debug_force_pending = 0; // test hook: every k-th ray slot takes the not-tame route (HIT_PENDING -> redo -> second pass)
+  int chunk_log2 = 26;     // pixel-samples in flight per chunk of a call, log2.  The small late stages of a chunk are latency-
+                           // bound (their length is the deepest ray's, not their work), so bigger chunks amortise them: 2^24 ->
+                           // 2^26 is +9 % on C4 (64 spp calls), +15 % on C5, +17 % on 256-spp C2 calls; 2^28 another 3-5 %.
+                           // Scratch is sized by the call (<= ~350 B per pixel-sample in flight: 23 GB of the 288 at 2^26)
   int launch_events = 0;   // 1: a pair of timing events around every trace launch (ezrt_last_render_ms's second figure; each
                            // record costs the stream ~5 us: -1.2 % on C2); 0: only the call's begin / end events
   int env_rgbe = 1;        // environment lookups through the 4-byte RGBE form of the map when it has an exact one (set_env)
@@ -132,6 +136,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"debug_stages", &Tuning::debug_stages, 0, 2},
                               {"env_rgbe", &Tuning::env_rgbe, 0, 1},
                               {"launch_events", &Tuning::launch_events, 0, 1},
+                              {"chunk_log2", &Tuning::chunk_log2, 12, 28},
                               {"redo_overlap", &Tuning::redo_overlap, 0, 1},
                               {"debug_force_pending", &Tuning::debug_force_pending, 0, 1 << 20},
                               {"audit_via_queue", &Tuning::audit_via_queue, 0, 2}};
@@ -1346,9 +1351,9 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
   const int nb = (int)s->blocks_host.size();
   HIP_TRY(hipEventRecord(s->ev_begin, st));
   if (nb > 0 && p->spp > 0) {
-    // frames per chunk: at most 2^24 pixel-samples in flight (sample buffer 256 MiB + queues)
+    // frames per chunk: at most 2^chunk_log2 pixel-samples in flight (see Tuning)
     const size_t per_frame = (size_t)nb * BLOCK;
-    size_t chunk = (size_t)(16u << 20) / per_frame;
+    size_t chunk = ((size_t)1 << s->tune.chunk_log2) / per_frame;
     if (chunk < 1) chunk = 1;
     if (chunk > p->spp) chunk = p->spp;
     const int use_mega = s->tune.megakernel;

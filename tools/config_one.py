@@ -6,7 +6,7 @@ from ezrt_amd import scene as S, scenes, trace
 hip = trace.hip()
 name = sys.argv[1]
 cfg = scenes.CONFIGS[name]
-spp = int(sys.argv[2]) if len(sys.argv) > 2 else {"C2": 64, "C3": 16, "C4": 16, "C5": 4}[name]
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else {"C2": 64, "C3": 64, "C4": 64, "C5": 16}[name]
 built = {"C2": lambda: scenes.bunny_scene(subdiv=2, hdr="shipped"), "C3": lambda: scenes.disney_grid_scene(subdiv=3, hdr="shipped"),
          "C4": lambda: scenes.p5_scene(subdiv=2, hdr="shipped"), "C5": lambda: scenes.mega_scene(hdr="shipped")}[name]()
 sc = built.upload(hip)

@@ -1,5 +1,5 @@
 """Throughput of the BASELINE.json configs on one GPU (C2 at full size; C3, C4, C5 at their full resolution and a
-reduced spp that still fills whole chunks): rays/s from the kernels' ray counter and hipEvent time of
+reduced spp that still fills a whole chunk of 2^26 pixel-samples): rays/s from the kernels' ray counter and hipEvent time of
 ezrt_render_device (frame buffer resident), plus the two f4 variants (integrator 52, sixteen Sobol dimensions).
 Prints one JSON object; `python tools/config_rates.py > gpurun_out/config_rates.json`, kept under profiles/rN/."""
 import json
@@ -64,11 +64,11 @@ def timed(f, *a, **k):
 b, s = timed(scenes.bunny_scene, subdiv=2, hdr="shipped")
 run("C2", b, C["C2"], 64, build_s=s)
 b, s = timed(scenes.disney_grid_scene, subdiv=3, hdr="shipped", )
-run("C3", b, C["C3"], 16, build_s=s)
+run("C3", b, C["C3"], 64, build_s=s)
 b4, s = timed(scenes.p5_scene, subdiv=2, hdr="shipped")
-run("C4", b4, C["C4"], 16, build_s=s)
-run("C4 / integrator 52 (anisotropic lobe sampled)", b4, C["C4"], 16, integrator=52)
+run("C4", b4, C["C4"], 64, build_s=s)
+run("C4 / integrator 52 (anisotropic lobe sampled)", b4, C["C4"], 64, integrator=52)
 b5, s = timed(scenes.mega_scene, hdr="shipped")
-run("C5 (8 Sobol dims, d & 7)", b5, C["C5"], 4, build_s=s)
-run("C5 (16 Sobol dims)", b5, C["C5"], 4, sobol_dims=16)
+run("C5 (8 Sobol dims, d & 7)", b5, C["C5"], 16, build_s=s)
+run("C5 (16 Sobol dims)", b5, C["C5"], 16, sobol_dims=16)
 print(json.dumps(out, indent=1))

@@ -12,7 +12,7 @@ for name in sys.argv[1:]:
     hold = name.endswith("+")   # "C2+": keep the scene alive instead of closing it
     name = name.rstrip("+")
     cfg = scenes.CONFIGS[name]
-    spp = {"C2": 64, "C3": 16, "C4": 16, "C5": 4}[name]
+    spp = {"C2": 64, "C3": 64, "C4": 64, "C5": 16}[name]
     if name not in built:
         built[name] = B[name]()
     sc = built[name].upload(hip)
