@@ -796,8 +796,9 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
       g.hits = pp.hits2[in].p;
       g.rq_d = queue(in).d;
       const bool compact = p->integrator == EZRT_INTEGRATOR_P5_SOBOL; // (compact_state<50>: see PathState)
-      g.st_slot = compact ? state(in).s1 : state(in).s2;
-      g.slot_comp = compact ? (b == 1 ? 0 : 3) : 3;
+      const bool mis1 = mis && b == 1; // (mis_stage1_state: the sample slot is s1.y)
+      g.st_slot = (compact || mis1) ? state(in).s1 : state(in).s2;
+      g.slot_comp = compact ? (b == 1 ? 0 : 3) : (mis1 ? 1 : 3);
       g.slot_stride = (compact && b == 1) ? 2 : 4;
       g.n_in = pp.qcounts.p + b;
       g.n_slots = (uint32_t)n_slots;

@@ -39,9 +39,14 @@ struct PathState { // SoA of float4, one slot per live path
   //   (tri0 = the primary hit's triangle if its emission is not all-zero bits, else 0xffffffff)
   //   into stages >= 2:  s0 = history.xyz, cosine   s1 = Lo.xyz, bits(sample slot)   s2 = f_r.xyz, bits(tri0)      48 B
   // (tri0 = the primary hit's triangle; Le0 is re-read from its material at the path's end)
+  // The MIS integrators (51, 52) carry the general state from stage 1 on, but INTO stage 1 -- the biggest stage, and its
+  // first pass is bound by streaming this state -- history = 1 and Lo = 0 are known as well:
+  //   s0 = f_r.xyz, cosine   s1 = pdf, bits(sample slot), bits(seed), bits(tri0)   s4 as above          48 B instead of 80
 };
 template <int INTEG>
 constexpr bool compact_state() { return INTEG == EZRT_INTEGRATOR_P5_SOBOL; }
+template <int INTEG, int STAGE>
+constexpr bool mis_stage1_state() { return integ_mis<INTEG>() && STAGE == 1; } // (see PathState)
 struct WfArgs {
   DevScene sc;
   EzrtRenderParams p;
@@ -217,6 +222,7 @@ EZD void shade_load(const WfArgs& a, const uint32_t i, const bool live, ShadeIn&
   constexpr bool MIS = integ_mis<INTEG>();
   constexpr bool B0 = (STAGE == 0);
   constexpr bool COMPACT = compact_state<INTEG>();
+  constexpr bool MIS1 = mis_stage1_state<INTEG, STAGE>();
   const EzrtRenderParams& p = a.p;
   const int b = a.bounce;
   // first-level loads: addresses depend on i only, so issue them all up front (one memory
@@ -231,7 +237,7 @@ EZD void shade_load(const WfArgs& a, const uint32_t i, const bool live, ShadeIn&
   int2 sh = make_int2(-1, 0);
   if (!B0) {
     if (PASS != 1) ro4 = a.rq_in.o[rslot]; // (only a surface interaction needs the ray origin)
-    if (!COMPACT) s3 = a.st_in.s3[ii];
+    if (!COMPACT && !MIS1) s3 = a.st_in.s3[ii];
     s0 = a.st_in.s0[ii];
     if (COMPACT && STAGE == 1) { // (bits(sample slot), bits(tri0)) only: 8-byte records in the s1 array
       const float2 q = reinterpret_cast<const float2*>(a.st_in.s1)[ii];
@@ -239,7 +245,7 @@ EZD void shade_load(const WfArgs& a, const uint32_t i, const bool live, ShadeIn&
     } else {
       s1 = a.st_in.s1[ii];
     }
-    if (!COMPACT || STAGE >= 2) s2 = a.st_in.s2[ii];
+    if ((!COMPACT || STAGE >= 2) && !MIS1) s2 = a.st_in.s2[ii];
     if (MIS) {
       s4 = a.st_in.s4[ii];
       sh = from_entry ? make_int2((int32_t)entry->w, 0) : a.hits[2u * ii];
@@ -255,8 +261,8 @@ EZD void shade_load(const WfArgs& a, const uint32_t i, const bool live, ShadeIn&
     if (PASS != 1) EZ_PIN4(ro4);
     EZ_PIN4(s0);
     EZ_PIN4(s1);
-    if (!COMPACT || STAGE >= 2) EZ_PIN4(s2);
-    if (!COMPACT) EZ_PIN4(s3);
+    if ((!COMPACT || STAGE >= 2) && !MIS1) EZ_PIN4(s2);
+    if (!COMPACT && !MIS1) EZ_PIN4(s3);
     if (MIS) {
       EZ_PIN4(s4);
       asm volatile("" : "+v"(sh.x), "+v"(sh.y));
@@ -347,6 +353,17 @@ EZD bool shade_body(const WfArgs& a, const uint32_t i, bool live, const ShadeIn&
       // Le0 = the primary hit's emission (getMaterial: texel 6 of its record), needed when the path ends; all-zero
       // bits (tri0 = none) for every non-emissive primary hit
       if (tri0 != 0xffffffffu) {
+        const float* e = sc.tri_ref + (size_t)tri0 * EZRT_TRI_FLOATS + 18;
+        Le0 = mk(e[0], e[1], e[2]);
+      }
+    } else if (mis_stage1_state<INTEG, STAGE>()) { // history = (1,1,1), Lo = (0,0,0): the initial values, untouched by bounce 0
+      f_r = mk(s0.x, s0.y, s0.z);
+      cosine = s0.w;
+      pdf = s1.x;
+      sslot = __float_as_uint(s1.y);
+      seed = __float_as_uint(s1.z);
+      tri0 = __float_as_uint(s1.w);
+      if (tri0 != 0xffffffffu) { // (as for the compact state above)
         const float* e = sc.tri_ref + (size_t)tri0 * EZRT_TRI_FLOATS + 18;
         Le0 = mk(e[0], e[1], e[2]);
       }
@@ -501,12 +518,16 @@ EZD bool shade_path(const WfArgs& a, const uint32_t i, bool live, Counters& ctr,
   return shade_body<INTEG, FULLCTR, PASS, STAGE>(a, i, live, in, ctr, n_samples, o);
 }
 
-// FORM: 0 = the general state, 1 = compact state into stage 1, 2 = compact state into stages >= 2 (see PathState)
+// FORM: 0 = the general state, 1 = compact state into stage 1, 2 = compact state into stages >= 2, 3 = the MIS integrators'
+// state into stage 1 (see PathState)
 template <bool MIS, int FORM>
 EZD void shade_store(const WfArgs& a, const ShadeOut& o, const uint32_t k) {
   if (FORM == 1) {
     a.st_out.s0[k] = make_float4(o.f_r.x, o.f_r.y, o.f_r.z, o.cosine);
     reinterpret_cast<float2*>(a.st_out.s1)[k] = make_float2(__uint_as_float(o.sslot), __uint_as_float(o.tri0));
+  } else if (FORM == 3) {
+    a.st_out.s0[k] = make_float4(o.f_r.x, o.f_r.y, o.f_r.z, o.cosine);
+    a.st_out.s1[k] = make_float4(o.pdf, __uint_as_float(o.sslot), __uint_as_float(o.seed), __uint_as_float(o.tri0));
   } else if (FORM == 2) {
     a.st_out.s0[k] = make_float4(o.history.x, o.history.y, o.history.z, o.cosine);
     a.st_out.s1[k] = make_float4(o.Lo.x, o.Lo.y, o.Lo.z, __uint_as_float(o.sslot));
@@ -530,7 +551,7 @@ EZD void shade_store(const WfArgs& a, const ShadeOut& o, const uint32_t k) {
   }
 }
 template <int INTEG, int STAGE>
-constexpr int store_form() { return compact_state<INTEG>() ? (STAGE == 0 ? 1 : 2) : 0; }
+constexpr int store_form() { return compact_state<INTEG>() ? (STAGE == 0 ? 1 : 2) : ((integ_mis<INTEG>() && STAGE == 0) ? 3 : 0); }
 // compaction of the surviving paths into the next queue: one ballot per wave, one atomic per workgroup
 template <bool MIS, int FORM>
 EZD void shade_emit(const WfArgs& a, const ShadeOut& o, uint32_t* alloc_lds) {
