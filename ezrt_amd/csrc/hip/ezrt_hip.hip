@@ -554,7 +554,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
   const size_t n_rays_max = n_slots * (mis ? 2 : 1);
   if (p->max_bounce > 32) return fail(EZRT_ERR_UNSUPPORTED, "max_bounce > 32: more stages than this build has queue counters for");
   for (int k = 0; k < 2; k++) {
-    HIP_TRY(pp.rq_o[k].ensure(n_rays_max));
+    HIP_TRY(pp.rq_o[k].ensure(n_slots)); // (one origin per path)
     HIP_TRY(pp.rq_d[k].ensure(n_rays_max));
     for (int j = 0; j < (mis ? 5 : 4); j++) HIP_TRY(pp.st[k][j].ensure(n_slots));
   }
@@ -698,7 +698,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     t.hits = pp.hits2[in].p;
     t.n_paths = pp.qcounts.p + b;
     t.rays_per_path = (mis && b > 0) ? 2u : 1u;
-    t.const_origin = b == 0 ? 1u : 0u;
+    t.const_origin = b == 0 ? 1u : (mis ? 2u : 0u); // (MIS: one stored origin per path, shared by its two rays)
     t.inner_rel = (!wide && b == 0 && tu.rel_boxes && s->n_inner > 0) ? pp.inner_rel.p : nullptr;
     t.origin[0] = p->eye[0];
     t.origin[1] = p->eye[1];

@@ -50,7 +50,8 @@ struct TraceQArgs {
   int2* hits;
   const uint32_t* n_paths; // device count; rays = n_paths * rays_per_path
   uint32_t rays_per_path;
-  uint32_t const_origin;   // 1: every ray of this queue starts at `origin` (primary rays); rq.o is not read
+  uint32_t const_origin;   // 1: every ray of this queue starts at `origin` (primary rays); rq.o is not read.  2: the two rays of a
+                           // path (MIS: shadow ray, bounce ray) share one stored origin, rq.o[slot >> 1].  0: rq.o[slot]
   float origin[3];
   const float4* inner_rel; // const_origin only (or NULL): sc.inner with every box already translated by -origin, i.e.
                            // (AA - S, BB - S) evaluated once per record instead of once per visit -- the same fp32
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
             if (a.redo_flag) a.redo_flag[rs] = 0u;
           }
           nx_slot = rs;
-          nx_o = a.const_origin ? make_float4(a.origin[0], a.origin[1], a.origin[2], 0.0f) : a.rq.o[rs];
+          nx_o = a.const_origin == 1u ? make_float4(a.origin[0], a.origin[1], a.origin[2], 0.0f) : a.rq.o[rs >> (a.const_origin >> 1)];
           nx_d = a.rq.d[rs];
         }
       }

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
           uint32_t rs = idx;
           if (a.slot_map) rs = a.slot_map[idx];
           nx_slot = rs;
-          if (!REL) nx_o = a.const_origin ? make_float4(a.origin[0], a.origin[1], a.origin[2], 0.0f) : a.rq.o[rs];
+          if (!REL) nx_o = a.const_origin == 1u ? make_float4(a.origin[0], a.origin[1], a.origin[2], 0.0f) : a.rq.o[rs >> (a.const_origin >> 1)];
           nx_d = a.rq.d[rs];
         }
       }

@@ -236,7 +236,7 @@ EZD void shade_load(const WfArgs& a, const uint32_t i, const bool live, ShadeIn&
   float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, s3 = s0, s4 = s0;
   int2 sh = make_int2(-1, 0);
   if (!B0) {
-    if (PASS != 1) ro4 = a.rq_in.o[rslot]; // (only a surface interaction needs the ray origin)
+    if (PASS != 1) ro4 = a.rq_in.o[ii]; // (only a surface interaction needs the ray origin; one per path)
     if (!COMPACT && !MIS1) s3 = a.st_in.s3[ii];
     s0 = a.st_in.s0[ii];
     if (COMPACT && STAGE == 1) { // (bits(sample slot), bits(tri0)) only: 8-byte records in the s1 array
@@ -541,9 +541,8 @@ EZD void shade_store(const WfArgs& a, const ShadeOut& o, const uint32_t k) {
   const bool shoot = !(o.flags & FLAG_TERMINATE);
   if (MIS) {
     a.st_out.s4[k] = make_float4(o.shadowC.x, o.shadowC.y, o.shadowC.z, __uint_as_float(o.flags));
-    a.rq_out.o[2u * k] = make_float4(o.P.x, o.P.y, o.P.z, 0.0f);
+    a.rq_out.o[k] = make_float4(o.P.x, o.P.y, o.P.z, 0.0f); // (one origin for the path's two rays: TraceQArgs::const_origin = 2)
     a.rq_out.d[2u * k] = make_float4(o.shadowL.x, o.shadowL.y, o.shadowL.z, (o.flags & FLAG_SHADOW_SHOT) ? 1.0f : 0.0f);
-    a.rq_out.o[2u * k + 1u] = make_float4(o.P.x, o.P.y, o.P.z, 0.0f);
     a.rq_out.d[2u * k + 1u] = make_float4(o.rayL.x, o.rayL.y, o.rayL.z, shoot ? 1.0f : 0.0f);
   } else {
     a.rq_out.o[k] = make_float4(o.P.x, o.P.y, o.P.z, 0.0f);
@@ -734,7 +733,7 @@ __global__ __launch_bounds__(BLOCK) void tail_kernel(WfArgs a, int32_t stack_ent
     ShadeIn in;
     const uint32_t rslot = MIS ? 2u * i + 1u : i;
     in.rd4 = a.rq_in.d[rslot];
-    in.ro4 = a.rq_in.o[rslot];
+    in.ro4 = a.rq_in.o[i];
     in.s0 = a.st_in.s0[i];
     in.s1 = a.st_in.s1[i];
     in.s2 = a.st_in.s2[i];
