@@ -473,8 +473,25 @@ EZD f3 tex_fetch_rgbe(const uint32_t* __restrict__ img, int W, int H, int filter
   if (iy0 < 0) iy0 = 0;
   if (ix1 > W - 1) ix1 = W - 1;
   if (iy1 > H - 1) iy1 = H - 1;
-  const uint32_t q00 = img[(size_t)iy0 * W + ix0], q10 = img[(size_t)iy0 * W + ix1];
-  const uint32_t q01 = img[(size_t)iy1 * W + ix0], q11 = img[(size_t)iy1 * W + ix1];
+  // The two texels of a row are neighbours (or, at the map's left / right edge, the same texel): ONE 8-byte load per row
+  // from the pair (bx, bx + 1) that contains them -- the bounce rays' lookups are scattered, so the stage is bound by
+  // the number of load requests, not by bytes.  (4-byte aligned: the struct says so.)
+  struct __attribute__((packed, aligned(4))) TexelPair {
+    uint32_t a, b;
+  };
+  uint32_t q00, q10, q01, q11;
+  if (W >= 2) {
+    int bx = ix0 < W - 2 ? ix0 : W - 2;
+    const TexelPair r0 = *reinterpret_cast<const TexelPair*>(img + (size_t)iy0 * W + bx);
+    const TexelPair r1 = *reinterpret_cast<const TexelPair*>(img + (size_t)iy1 * W + bx);
+    q00 = ix0 == bx ? r0.a : r0.b;
+    q10 = ix1 == bx ? r0.a : r0.b;
+    q01 = ix0 == bx ? r1.a : r1.b;
+    q11 = ix1 == bx ? r1.a : r1.b;
+  } else {
+    q00 = img[(size_t)iy0 * W + ix0], q10 = img[(size_t)iy0 * W + ix1];
+    q01 = img[(size_t)iy1 * W + ix0], q11 = img[(size_t)iy1 * W + ix1];
+  }
   f3 top = mix3(rgbe_texel(q00), rgbe_texel(q10), fx);
   f3 bot = mix3(rgbe_texel(q01), rgbe_texel(q11), fx);
   return mix3(top, bot, fy);
