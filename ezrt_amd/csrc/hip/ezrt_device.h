@@ -71,6 +71,8 @@ struct DevScene {
   const uint32_t* hdr_rgbe; // the same map as R | G << 8 | B << 16 | E << 24 when EVERY texel is exactly (m / 256) 2^(E - 128)
                             // per channel -- true by construction for maps HDRLoader decoded (hdrloader.cpp:97-114) -- else NULL
   const float4* cache; // (x/w, y/h, pdf, 0)
+  const float2* cache_xy; // the same cache as two planes (or NULL): (x/w, y/h) for SampleHdr, pdf for hdrPdf -- the two
+  const float* cache_pdf; // texels a bilinear lookup takes from a row are then ONE 16- or 8-byte load (tex_fetch_xy / _pdf)
   int32_t env_w, env_h, env_filter;
   uint32_t sobol_mask; // 7: Sobol dimensions wrap d & 7 (the reference's table), 15: sixteen dimensions (ezrt_scene_set_sampler)
 };
@@ -497,6 +499,50 @@ EZD f3 tex_fetch_rgbe(const uint32_t* __restrict__ img, int W, int H, int filter
   return mix3(top, bot, fy);
 }
 
+// Bilinear lookups in the two planes of the env cache (DevScene::cache_xy, cache_pdf): tex_fetch's arithmetic on the
+// components the caller uses, with a row's two texels -- neighbours, or the same texel at the map's edge -- taken from
+// the pair (bx, bx + 1) with one load.  W >= 2.
+EZD void bilinear_taps(int W, int H, float u, float v, int& ix0, int& ix1, int& iy0, int& iy1, float& fx, float& fy) {
+  float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+  float x0 = ez_floor(x), y0 = ez_floor(y);
+  fx = x - x0;
+  fy = y - y0;
+  ix0 = (int)x0, iy0 = (int)y0, ix1 = ix0 + 1, iy1 = iy0 + 1;
+  if (ix0 < 0) ix0 = 0;
+  if (iy0 < 0) iy0 = 0;
+  if (ix1 > W - 1) ix1 = W - 1;
+  if (iy1 > H - 1) iy1 = H - 1;
+}
+EZD float tex_fetch_pdf(const float* __restrict__ img, int W, int H, float u, float v) {
+  struct __attribute__((packed, aligned(4))) Pair {
+    float a, b;
+  };
+  int ix0, ix1, iy0, iy1;
+  float fx, fy;
+  bilinear_taps(W, H, sane01(u), sane01(v), ix0, ix1, iy0, iy1, fx, fy);
+  const int bx = ix0 < W - 2 ? ix0 : W - 2;
+  const Pair r0 = *reinterpret_cast<const Pair*>(img + (size_t)iy0 * W + bx);
+  const Pair r1 = *reinterpret_cast<const Pair*>(img + (size_t)iy1 * W + bx);
+  const float p00 = ix0 == bx ? r0.a : r0.b, p10 = ix1 == bx ? r0.a : r0.b;
+  const float p01 = ix0 == bx ? r1.a : r1.b, p11 = ix1 == bx ? r1.a : r1.b;
+  return ez_mix(ez_mix(p00, p10, fx), ez_mix(p01, p11, fx), fy);
+}
+EZD void tex_fetch_xy(const float2* __restrict__ img, int W, int H, float u, float v, float& cx, float& cy) {
+  struct __attribute__((aligned(8))) Pair {
+    float2 a, b;
+  };
+  int ix0, ix1, iy0, iy1;
+  float fx, fy;
+  bilinear_taps(W, H, sane01(u), sane01(v), ix0, ix1, iy0, iy1, fx, fy);
+  const int bx = ix0 < W - 2 ? ix0 : W - 2;
+  const Pair r0 = *reinterpret_cast<const Pair*>(img + (size_t)iy0 * W + bx);
+  const Pair r1 = *reinterpret_cast<const Pair*>(img + (size_t)iy1 * W + bx);
+  const float2 p00 = ix0 == bx ? r0.a : r0.b, p10 = ix1 == bx ? r0.a : r0.b;
+  const float2 p01 = ix0 == bx ? r1.a : r1.b, p11 = ix1 == bx ? r1.a : r1.b;
+  cx = ez_mix(ez_mix(p00.x, p10.x, fx), ez_mix(p01.x, p11.x, fx), fy);
+  cy = ez_mix(ez_mix(p00.y, p10.y, fx), ez_mix(p01.y, p11.y, fx), fy);
+}
+
 // toSphericalCoord: P5/fsh:684-690
 EZD void to_spherical(f3 v, float& u, float& w) {
   u = ez_atan2(v.z, v.x);
@@ -523,7 +569,13 @@ EZD f3 hdr_color(const DevScene& sc, f3 L, float env_clamp, Counters& ctr) {
 template <bool FULLCTR>
 EZD f3 sample_hdr(const DevScene& sc, float xi1, float xi2, Counters& ctr) {
   if (FULLCTR) ctr.envcache++;
-  f3 c = tex_fetch(sc.cache, sc.env_w, sc.env_h, sc.env_filter, xi1, xi2);
+  f3 c;
+  if (sc.cache_xy && sc.env_filter == EZRT_FILTER_BILINEAR) {
+    c.z = 0.0f;
+    tex_fetch_xy(sc.cache_xy, sc.env_w, sc.env_h, xi1, xi2, c.x, c.y);
+  } else {
+    c = tex_fetch(sc.cache, sc.env_w, sc.env_h, sc.env_filter, xi1, xi2);
+  }
   float x = c.x, y = 1.0f - c.y;
   float phi = 2.0f * PI * (x - 0.5f);
   float theta = PI * (y - 0.5f);
@@ -538,7 +590,8 @@ EZD float hdr_pdf(const DevScene& sc, f3 L, Counters& ctr) {
   if (FULLCTR) ctr.envcache++;
   float u, v;
   to_spherical(normalize(L), u, v);
-  float pdf = tex_fetch(sc.cache, sc.env_w, sc.env_h, sc.env_filter, u, v).z;
+  float pdf = (sc.cache_pdf && sc.env_filter == EZRT_FILTER_BILINEAR) ? tex_fetch_pdf(sc.cache_pdf, sc.env_w, sc.env_h, u, v)
+                                                                     : tex_fetch(sc.cache, sc.env_w, sc.env_h, sc.env_filter, u, v).z;
   float theta = PI * (0.5f - v);
   float sin_theta = ez_max(ez_sin(theta), 1e-10f);
   int res = sc.env_w;
@@ -565,7 +618,8 @@ EZD void hdr_color_pdf(const DevScene& sc, f3 L, float env_clamp, Counters& ctr,
     if (env_clamp > 0.0f) c = mk(ez_min(c.x, env_clamp), ez_min(c.y, env_clamp), ez_min(c.z, env_clamp));
     color = c;
   }
-  float pdf = tex_fetch(sc.cache, sc.env_w, sc.env_h, sc.env_filter, u, v).z;
+  float pdf = (sc.cache_pdf && sc.env_filter == EZRT_FILTER_BILINEAR) ? tex_fetch_pdf(sc.cache_pdf, sc.env_w, sc.env_h, u, v)
+                                                                     : tex_fetch(sc.cache, sc.env_w, sc.env_h, sc.env_filter, u, v).z;
   float theta = PI * (0.5f - v);
   float sin_theta = ez_max(ez_sin(theta), 1e-10f);
   int res = sc.env_w;

@@ -103,6 +103,7 @@ struct Tuning {
                            // Scratch is sized by the call (<= ~350 B per pixel-sample in flight: 23 GB of the 288 at 2^26)
   int launch_events = 0;   // 1: a pair of timing events around every trace launch (ezrt_last_render_ms's second figure; each
                            // record costs the stream ~5 us: -1.2 % on C2); 0: only the call's begin / end events
+  int env_planes = 1;      // the env cache as an (x, y) plane and a pdf plane for bilinear lookups (one load per row)
   int env_rgbe = 1;        // environment lookups through the 4-byte RGBE form of the map when it has an exact one (set_env)
   int audit_via_queue = 0; // 1: ezrt_query_hits and ezrt_render_paths run through the TIMED kernels (traceq_kernel with
                            // the template, LDS layout, stealing and redo launch of a render call + the streaming shading
@@ -135,6 +136,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"tail_stage", &Tuning::tail_stage, 0, 64},
                               {"debug_stages", &Tuning::debug_stages, 0, 2},
                               {"env_rgbe", &Tuning::env_rgbe, 0, 1},
+                              {"env_planes", &Tuning::env_planes, 0, 1},
                               {"launch_events", &Tuning::launch_events, 0, 1},
                               {"chunk_log2", &Tuning::chunk_log2, 12, 28},
                               {"redo_overlap", &Tuning::redo_overlap, 0, 1},
@@ -194,6 +196,8 @@ struct EzrtScene {
   int stack_need4 = 1;        // LDS stack rows the 4-wide traversal can need (exact worst case over hit patterns)
   uint32_t root4 = 0;
   DevBuf<float4> hdr, cache;
+  DevBuf<float2> cache_xy; // the cache as two planes (bilinear lookups: one load per row; knob env_planes)
+  DevBuf<float> cache_pdf;
   DevBuf<uint32_t> hdr_rgbe; // RGBE form of hdr (has_rgbe)
   bool has_rgbe = false;
   uint32_t root_ref = 0;
@@ -235,6 +239,8 @@ struct EzrtScene {
     d.hdr = hdr.p;
     d.hdr_rgbe = (has_rgbe && tune.env_rgbe) ? hdr_rgbe.p : nullptr;
     d.cache = has_cache ? cache.p : nullptr;
+    d.cache_xy = (has_cache && tune.env_planes && env_w >= 2) ? cache_xy.p : nullptr;
+    d.cache_pdf = (has_cache && tune.env_planes && env_w >= 2) ? cache_pdf.p : nullptr;
     d.env_w = env_w;
     d.env_h = env_h;
     d.env_filter = env_filter;
@@ -1329,6 +1335,18 @@ int ezrt_scene_set_env(EzrtScene* s, const float* hdr, const float* cache, int w
     for (size_t i = 0; i < n; i++) tmp[i] = make_float4(cache[i * 3], cache[i * 3 + 1], cache[i * 3 + 2], 0.0f);
     HIP_TRY(s->cache.ensure(n));
     HIP_TRY(hipMemcpy(s->cache.p, tmp.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+    {
+      std::vector<float2> xy(n);
+      std::vector<float> pdf(n);
+      for (size_t i = 0; i < n; i++) {
+        xy[i] = make_float2(cache[i * 3], cache[i * 3 + 1]);
+        pdf[i] = cache[i * 3 + 2];
+      }
+      HIP_TRY(s->cache_xy.ensure(n));
+      HIP_TRY(s->cache_pdf.ensure(n));
+      HIP_TRY(hipMemcpy(s->cache_xy.p, xy.data(), n * sizeof(float2), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(s->cache_pdf.p, pdf.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    }
     s->has_cache = true;
   }
   s->env_w = w;
