@@ -96,6 +96,8 @@ struct Tuning {
   int redo_overlap = 1;    // the redo launch of a stage (exact ties, rays that are not tame: a handful of rays, but ~50 us of
                            // dependent traversal steps) runs on a side stream under the stage's first shading pass; the
                            // second pass waits for it (0: in line, before any shading)
+  int debug_oom_above = 0;     // test hook: chunk scratch for more than this many pixel-samples is reported as out of memory (exercises the
+                               // smaller-chunk retry of ezrt_render_device)
   int debug_force_pending = 0; // test hook: every k-th ray slot takes the not-tame route (HIT_PENDING -> redo -> second pass)
   int chunk_log2 = 26;     // pixel-samples in flight per chunk of a call, log2.  The small late stages of a chunk are latency-
                            // bound (their length is the deepest ray's, not their work), so bigger chunks amortise them: 2^24 ->
@@ -141,6 +143,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"chunk_log2", &Tuning::chunk_log2, 12, 28},
                               {"redo_overlap", &Tuning::redo_overlap, 0, 1},
                               {"debug_force_pending", &Tuning::debug_force_pending, 0, 1 << 20},
+                              {"debug_oom_above", &Tuning::debug_oom_above, 0, 1 << 30},
                               {"audit_via_queue", &Tuning::audit_via_queue, 0, 2}};
 Tuning tuning_from_env() {
   Tuning t;
@@ -547,6 +550,35 @@ void launch_shade(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
   }
 }
 
+// The queues of one chunk (n_slots pixel-samples in flight).  hipErrorOutOfMemory leaves the pipe consistent (a DevBuf that
+// failed to grow is empty), so the caller can retry with a smaller chunk.
+hipError_t ensure_chunk_scratch(EzrtScene* s, Pipe& pp, size_t n_slots, bool mis, hipStream_t st) {
+  if (s->tune.debug_oom_above > 0 && n_slots > (size_t)s->tune.debug_oom_above) return hipErrorOutOfMemory; // (test hook)
+  const size_t n_rays_max = n_slots * (mis ? 2 : 1);
+#define EZ_ENSURE(x)                   \
+  do {                                 \
+    hipError_t e_ = (x);               \
+    if (e_ != hipSuccess) return e_;   \
+  } while (0)
+  EZ_ENSURE(pp.samples.ensure(n_slots));
+  for (int k = 0; k < 2; k++) {
+    EZ_ENSURE(pp.rq_o[k].ensure(n_slots)); // (one origin per path)
+    EZ_ENSURE(pp.rq_d[k].ensure(n_rays_max));
+    for (int j = 0; j < (mis ? 5 : 4); j++) EZ_ENSURE(pp.st[k][j].ensure(n_slots));
+  }
+  EZ_ENSURE(pp.hits2[0].ensure(n_rays_max));
+  EZ_ENSURE(pp.hits2[1].ensure(n_rays_max));
+  EZ_ENSURE(pp.redo_slots.ensure(n_rays_max));
+  if (pp.redo_flag.n < n_rays_max) { // zeroed once; every entry set is cleared again by the redo launch
+    EZ_ENSURE(pp.redo_flag.ensure(n_rays_max));
+    EZ_ENSURE(hipMemsetAsync(pp.redo_flag.p, 0, n_rays_max * sizeof(uint32_t), st));
+  }
+  EZ_ENSURE(pp.defer_list.ensure(n_slots + (size_t)2048 * 1024)); // per-workgroup regions: iterations x SHADE_BLOCK each
+  EZ_ENSURE(pp.defer_count.ensure(2048u * 1024u / SHADE_BLOCK));
+#undef EZ_ENSURE
+  return hipSuccess;
+}
+
 struct PathLogTarget { // ezrt_render_paths through the timed pipeline (audit_via_queue)
   int32_t* tri = nullptr;
   float* t = nullptr;
@@ -557,27 +589,13 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
   const bool mis = p->integrator == EZRT_INTEGRATOR_P5_MIS || p->integrator == EZRT_INTEGRATOR_P5_MIS_ANISO;
   const bool full = s->instr > 0;
   const size_t n_slots = (size_t)nb * BLOCK * nf;
-  const size_t n_rays_max = n_slots * (mis ? 2 : 1);
   if (p->max_bounce > 32) return fail(EZRT_ERR_UNSUPPORTED, "max_bounce > 32: more stages than this build has queue counters for");
-  for (int k = 0; k < 2; k++) {
-    HIP_TRY(pp.rq_o[k].ensure(n_slots)); // (one origin per path)
-    HIP_TRY(pp.rq_d[k].ensure(n_rays_max));
-    for (int j = 0; j < (mis ? 5 : 4); j++) HIP_TRY(pp.st[k][j].ensure(n_slots));
-  }
-  HIP_TRY(pp.hits2[0].ensure(n_rays_max));
-  HIP_TRY(pp.hits2[1].ensure(n_rays_max));
-  HIP_TRY(pp.redo_slots.ensure(n_rays_max));
-  if (pp.redo_flag.n < n_rays_max) { // zeroed once; every entry set is cleared again by the redo launch
-    HIP_TRY(pp.redo_flag.ensure(n_rays_max));
-    HIP_TRY(hipMemsetAsync(pp.redo_flag.p, 0, n_rays_max * sizeof(uint32_t), st));
-  }
+  HIP_TRY(ensure_chunk_scratch(s, pp, n_slots, mis, st)); // (a no-op after ezrt_render_device's sizing pass)
   // [0..63] paths per stage, [64..99] queue heads, [100..119] debug, [120,121] packet redo,
   // [128..] redo counts per stage, [192..] redo queue heads per stage
   constexpr size_t HEAD_SLOT = (size_t)TRACE_HEADS * TRACE_HEAD_STRIDE; // launch slots: stage b, redo 40 + b, packet redo 80
   HIP_TRY(pp.qheads.ensure(81 * HEAD_SLOT)); // (both zeroed by raygen_kernel: ChunkPrologue)
   HIP_TRY(pp.qcounts.ensure(320));
-  HIP_TRY(pp.defer_list.ensure(n_slots + (size_t)2048 * 1024)); // per-workgroup regions: iterations x SHADE_BLOCK each
-  HIP_TRY(pp.defer_count.ensure(2048u * 1024u / SHADE_BLOCK));
   {
     int rc_cu = ensure_num_cus(s);
     if (rc_cu) return rc_cu;
@@ -1382,6 +1400,18 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
       size_t half = (p->spp + 1) / 2;
       if (s->tune.sub_frames > 0 && (size_t)s->tune.sub_frames < half) half = (size_t)s->tune.sub_frames;
       if (chunk > half) chunk = half;
+    }
+    if (!use_mega) { // size the chunk's queues now: if they do not fit, halve the chunk (same results, more launches)
+      const bool mis = p->integrator == EZRT_INTEGRATOR_P5_MIS || p->integrator == EZRT_INTEGRATOR_P5_MIS_ANISO;
+      for (;;) {
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < n_pipes && e == hipSuccess; i++) e = ensure_chunk_scratch(s, s->pipe[i], per_frame * chunk, mis, st);
+        if (e == hipSuccess) break;
+        (void)hipGetLastError();
+        if (e != hipErrorOutOfMemory || chunk <= 1)
+          return fail(EZRT_ERR_DEVICE, "render scratch for %zu pixel-samples in flight: %s", per_frame * chunk, hipGetErrorString(e));
+        chunk = (chunk + 1) / 2;
+      }
     }
     const size_t lds = stack_lds_bytes(s);
     uint32_t k = 0;
