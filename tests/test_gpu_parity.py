@@ -202,6 +202,23 @@ def test_full_size_bunny_70k_properties_and_sampled_parity(hip, oracle):
     assert crop[..., :3].max() > 0.5
 
 
+def _same_up_to_nan_payload(a, b):
+    """Bit equality, except that a NaN equals a NaN (sign and payload of a NaN are not part of the contract)."""
+    return bool(((_bits(a) == _bits(b)) | (np.isnan(a) & np.isnan(b))).all())
+
+
+@pytest.mark.parametrize("integ", [51, 52])
+def test_c4_at_full_resolution_equals_the_oracle(hip, oracle, integ):
+    """BASELINE.json's C4 (chapter 5's scene, 1024x1024, MIS, 2 bounces) at full resolution and a reduced spp: the MIS
+    integrators' stage-1 state, shared ray origins, env planes and multi-megasample chunks, against the oracle on the bits."""
+    bs = scenes.p5_scene(subdiv=2, hdr="shipped")
+    eye, cam = S.camera(*scenes.CONFIGS["C4"]["camera"])
+    p = trace.make_params(1024, 1024, eye, cam, integ, 2, spp=6)
+    got, want = bs.upload(hip).render(p), bs.upload(oracle).render(p)
+    assert _same_up_to_nan_payload(got, want)
+    assert np.isfinite(want[..., :3]).mean() > 0.999 and float(want[..., :3][np.isfinite(want[..., :3])].max()) > 0.5
+
+
 @pytest.mark.parametrize("integ", [50, 51])
 def test_eight_bounces_wrap_the_sobol_table(hip, oracle, bunny_small, integ):
     """BASELINE.json's stress config asks for 8 bounces; the shader's table has 8 dimensions = 4
