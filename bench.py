@@ -281,6 +281,30 @@ def main():
                                             "linf_vs_n_gpu_frame": float(torch.nan_to_num(one - final, nan=0.0, posinf=0.0, neginf=0.0).abs().max()) if not weak else None,
                                             "non_finite_pixels": int((~torch.isfinite(one[..., :3]).all(dim=2)).sum())}
             barrier()
+            if not weak:
+                # the weak-scaling variant of the same line: spp x N, so every GPU keeps the 1-GPU number of pixel-samples
+                # (the frame is then a different, N times deeper one: an extra field, never `value`)
+                pw = params((rank, world), n_spp=cfg["spp"] * world)
+                sc.set_option("launch_events", 0)
+                wacc = torch.zeros_like(accum)
+                def wstep():
+                    sc.render_device(pw, wacc.data_ptr(), stream)
+                    tiles.gather_frame(wacc, plan, rank, dist, via_cpu=(backend != "nccl"), lib=hip.lib)
+                wstep()
+                torch.cuda.synchronize()
+                sc.counters_reset()
+                barrier()
+                tw = time.perf_counter()
+                for _ in range(2):
+                    wstep()
+                torch.cuda.synchronize()
+                barrier()
+                wt = torch.tensor([time.perf_counter() - tw, float(sc.counters()["rays"])], dtype=torch.float64, device=tdev)
+                wmax = wt.clone()
+                dist.all_reduce(wmax, op=dist.ReduceOp.MAX)
+                dist.all_reduce(wt, op=dist.ReduceOp.SUM)
+                mg["weak_variant"] = {"spp": cfg["spp"] * world, "ms_per_step": round(float(wmax[0]) / 2 * 1e3, 3),
+                                      "Mrays_s": round(float(wt[1]) / float(wmax[0]) / 1e6, 2)}
         out["multi_gpu"] = mg
 
     if rank == 0 and world == 1:
