@@ -176,18 +176,19 @@ def main():
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     plan = tiles.TilePlan(W, H, args.tile, args.tile, world) if world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
-    gather_s = []
+
+    gather_ev = []
 
     def step():
         sc.render_device(p, accum.data_ptr(), stream)
         if world > 1:
-            if rank == 0:
-                torch.cuda.synchronize()
-                tg = time.perf_counter()
+            if rank == 0:   # (events on the launch stream, read after the timed loop: no host sync inside it)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             out_img = tiles.gather_frame(accum, plan, rank, dist, via_cpu=(backend != "nccl"), lib=hip.lib)
             if rank == 0:
-                torch.cuda.synchronize()
-                gather_s.append(time.perf_counter() - tg)   # includes waiting for the slowest rank
+                e1.record()
+                gather_ev.append((e0, e1))   # rank 0's render done -> frame assembled: includes waiting for the slowest rank
             return out_img
         return accum
 
@@ -199,7 +200,7 @@ def main():
         step()
     torch.cuda.synchronize()
     sc.counters_reset()
-    gather_s.clear()
+    gather_ev.clear()
     step_ms = []
     barrier()
     torch.cuda.synchronize()
@@ -209,6 +210,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    gather_s = [a.elapsed_time(b) * 1e-3 for a, b in gather_ev]
     # per-step GPU times (hipEvents on the launch stream; reading them synchronises, so this is a separate, untimed
     # pass of the same step): median of 7 -- (all kernels, the trace launches, number of trace launches)
     rays_timed = sc.counters()["rays"]
