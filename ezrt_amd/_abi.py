@@ -68,6 +68,7 @@ TRACE_ABI = {
     "ezrt_scene_stats": (C.c_int, [C.c_void_p, c_int64_p]),
     "ezrt_debug_math": (C.c_int, [C.c_int, c_float_p, c_float_p, C.c_int, c_float_p]),
     "ezrt_last_error": (C.c_char_p, []),
+    "ezrt_trim": (C.c_int, []),
     "ezrt_backend": (C.c_char_p, []),
 }
 

@@ -1276,6 +1276,8 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
   return 0;
 }
 
+int ezrt_trim(void) { return ezh::stream_pool_trim(); }
+
 void ezrt_scene_destroy(EzrtScene* s) {
   if (!s) return;
   if (s->ev_begin) {

@@ -51,6 +51,23 @@ inline void stream_park(hipStream_t st, bool high_priority, int device) {
   g_stream_pool.push_back({device, high_priority, st});
 }
 
+// ezrt_trim: destroy every parked stream (the application is about to reset the device, or is done creating scenes).
+inline int stream_pool_trim() {
+  std::vector<PooledStream> all;
+  {
+    std::lock_guard<std::mutex> lock(g_stream_pool_mu);
+    all.swap(g_stream_pool);
+  }
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  for (const PooledStream& q : all) {
+    (void)hipSetDevice(q.device);
+    (void)hipStreamDestroy(q.st);
+  }
+  (void)hipSetDevice(prev);
+  return (int)all.size();
+}
+
 inline size_t stream_pool_size() {
   std::lock_guard<std::mutex> lock(g_stream_pool_mu);
   return g_stream_pool.size();

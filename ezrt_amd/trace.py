@@ -174,6 +174,10 @@ class TraceLib:
     def frame(self, width, height):
         return Frame(self, width, height)
 
+    def trim(self):
+        """ezrt_trim: destroy the streams parked by destroyed scenes; returns how many."""
+        return int(self.lib.ezrt_trim())
+
     def backend(self):
         return self.lib.ezrt_backend().decode()
 

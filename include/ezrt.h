@@ -179,6 +179,10 @@ int ezrt_scene_stats(EzrtScene* s, int64_t out[6]);
 int ezrt_debug_math(int op, const float* a, const float* b, int n, float* out);
 
 const char* ezrt_last_error(void);
+/* Optional: release what the library keeps between scenes -- the HIP streams of destroyed scenes, which are parked for
+ * the next scene on the same device instead of destroyed.  Returns the number of streams destroyed.  Call
+ * it before hipDeviceReset, or to hand the streams back when no further scene will be created. */
+int ezrt_trim(void);
 const char* ezrt_backend(void); /* "hip:gfx950" or "oracle:cpu" */
 
 #ifdef __cplusplus

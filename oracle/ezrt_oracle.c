@@ -102,6 +102,7 @@ static int fail(int code, const char* msg) {
   return code;
 }
 const char* ezrt_last_error(void) { return g_err; }
+int ezrt_trim(void) { return 0; } /* (nothing is cached between scenes on the CPU) */
 const char* ezrt_backend(void) { return "oracle:cpu"; }
 
 /* per-thread counters, merged after a parallel region */

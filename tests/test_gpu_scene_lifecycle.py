@@ -58,3 +58,20 @@ def test_two_scenes_alive_at_once_have_their_own_streams(hip):
     assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32))
     assert np.array_equal(fa.view(np.uint32), fc.view(np.uint32))
     assert np.array_equal(fa.view(np.uint32), fb2.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_trim_destroys_the_parked_streams_and_scenes_still_work_afterwards(hip):
+    from ezrt_amd import scene as S, scenes, trace
+    bs = scenes.bunny_scene(subdiv=0, hdr="shipped")
+    eye, cam = S.camera(30, 10, 4.0)
+    p = trace.make_params(96, 96, eye, cam, 50, 3, spp=2)
+    a = bs.upload(hip)
+    fa = a.render(p)
+    a.close()
+    assert hip.trim() >= 2      # a's two stream pairs were parked by close()
+    assert hip.trim() == 0
+    b = bs.upload(hip)          # creates its own streams again
+    fb = b.render(p)
+    b.close()
+    assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32))
