@@ -99,6 +99,9 @@ struct Tuning {
   int debug_oom_above = 0;     // test hook: chunk scratch for more than this many pixel-samples is reported as out of memory (exercises the
                                // smaller-chunk retry of ezrt_render_device)
   int debug_force_pending = 0; // test hook: every k-th ray slot takes the not-tame route (HIT_PENDING -> redo -> second pass)
+  int shade_wgs = 0;       // workgroups of a shading launch, each looping over its share of the queue (0: 12 per CU = three full
+                           // rounds of the first pass at 4 workgroups per CU and four of the second at 3; 4096 left the second
+                           // pass with a third of a round at its end: -1.2 % on C2)
   int chunk_log2 = 26;     // pixel-samples in flight per chunk of a call, log2.  The small late stages of a chunk are latency-
                            // bound (their length is the deepest ray's, not their work), so bigger chunks amortise them: 2^24 ->
                            // 2^26 is +9 % on C4 (64 spp calls), +15 % on C5, +17 % on 256-spp C2 calls; 2^28 another 3-5 %.
@@ -140,6 +143,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"env_rgbe", &Tuning::env_rgbe, 0, 1},
                               {"env_planes", &Tuning::env_planes, 0, 1},
                               {"launch_events", &Tuning::launch_events, 0, 1},
+                              {"shade_wgs", &Tuning::shade_wgs, 0, 4096},
                               {"chunk_log2", &Tuning::chunk_log2, 12, 28},
                               {"redo_overlap", &Tuning::redo_overlap, 0, 1},
                               {"debug_force_pending", &Tuning::debug_force_pending, 0, 1 << 20},
@@ -693,7 +697,9 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
   const int use_packet = tu.packet, packet_budget = tu.packet_budget, debug_stages = tu.debug_stages;
   const unsigned trace_grid_full = cfg.grid_full;
   unsigned shade_grid = (unsigned)((n_slots + SHADE_BLOCK - 1) / SHADE_BLOCK);
-  const unsigned shade_grid_max = 2048u * 1024u / SHADE_BLOCK; // 8 workgroup-iterations' worth of resident threads
+  unsigned shade_grid_max = s->tune.shade_wgs > 0 ? (unsigned)s->tune.shade_wgs : (unsigned)(12 * s->num_cus);
+  if (shade_grid_max > 4096u) shade_grid_max = 4096u; // (the defer lists are sized for that)
+  if (shade_grid_max < 1u) shade_grid_max = 1u;
   if (shade_grid > shade_grid_max) shade_grid = shade_grid_max;
 
   const int tail_from = (!full && !plog && !debug_stages && tu.tail_stage >= 2) ? tu.tail_stage : (1 << 30);
