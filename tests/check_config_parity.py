@@ -1,4 +1,4 @@
-"""tools/check_config_parity.py C4 [spp]: one BASELINE config at its full resolution, product (libezrt_hip.so) against the CPU
+"""tests/check_config_parity.py C4 [spp]: one BASELINE config at its full resolution, product (libezrt_hip.so) against the CPU
 oracle, bit for bit (test infrastructure: loads oracle/libezrt_oracle.so).  The -m gpu tests do this at sizes the oracle
 finishes in seconds; this is the same comparison at full size, run by hand on the GPU box."""
 import ctypes, os, sys, time
