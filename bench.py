@@ -8,13 +8,21 @@ map = the reference's only shipped HDR (P4/HDR/peppermint_powerplant_4k.hdr, 102
 full render of that frame (64 spp) through libezrt_hip.so; scene, env map and the frame buffer are resident in HBM
 before the timed region.  ray := one hitBVH call, counted by the kernels.
 
-N > 1 (one process per GPU, torchrun): workload C4 = BASELINE.json configs[3], the config BASELINE names for 8 GPUs:
-the P5 scene (Bunny with the teapot's material, near-mirror floor), P5 preset camera (rot 90, up 10, r 2), integrator
-51 (env importance sampling + MIS), 2 bounces, 1024x1024, 256 spp -- a FIXED frame split into 16x16 tiles dealt
-round-robin to the ranks ("scaling": "strong"); the scene is replicated, every rank traces all spp of its tiles and
-ONE gather of the packed tiles to rank 0 over RCCL closes the frame.  Extra fields report per-rank render times, the
-gather time, the imbalance, the same frame rendered by rank 0 alone (so the line carries its own 1-GPU reference),
-and the weak-scaling variant (spp x N).  `--workload c2|c4` overrides the choice for any N.
+N > 1 (one process per GPU, torchrun): the SAME workload, so that the per-N values of a scaling run are comparable:
+the C2 frame is cut into 16x16 tiles dealt round-robin to the ranks, the scene is replicated, every rank traces all
+spp of its tiles and ONE gather of the packed tiles to rank 0 over RCCL closes the frame.  Default "scaling": "weak"
+(spp x N: every GPU keeps the 1-GPU number of pixel-samples, the units are pixel-samples and they shard with no
+data-path collective before the closing gather); `--scaling strong` splits the fixed 64-spp frame N ways instead.
+Extra fields report per-rank render times, the gather time, the imbalance, the same frame rendered by rank 0 alone
+with a bitwise comparison (so the line carries its own 1-GPU reference), and BASELINE.json configs[3] (C4: P5 scene,
+integrator 51 = env importance sampling + MIS, 2 bounces, 1024x1024, 256 spp) as a FIXED frame split N ways
+(`c4_strong_variant`).  `--workload c2|c4` picks the main workload for any N.
+
+Timing (VERDICT r2 / SURVEY 8(d) "median of >= 5 runs"): after W warm-up steps the script times `--windows` (default 7)
+windows of EXACTLY K steps, each bracketed by barrier + synchronize on both sides and reduced with MAX over ranks;
+`value` and `ms_per_step` come from the MEDIAN window, every window is in the line (`timing.window_ms`), and so are the
+per-step GPU times of the slowest window (stream events, no host synchronisation inside a window), the host-side
+enqueue time per step and `wall_over_gpu`, so that a host-side stall or a clock ramp is visible instead of averaged in.
 
 Prints one JSON line on rank 0 (contract in the task statement) with `roofline` and, at N = 1, `cpu_baseline`
 (the CPU oracle timed on a bounded sample of the same workload).
@@ -107,9 +115,10 @@ def main():
     ap.add_argument("--subdiv", type=int, default=2)
     ap.add_argument("--tile", type=int, default=16)
     ap.add_argument("--env", choices=("shipped", "synthetic"), default="shipped")
-    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
-                    help="N > 1 -- strong (default): the fixed frame is split N ways; weak: spp x N, so every GPU keeps the "
-                         "1-GPU number of pixel-samples")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="weak",
+                    help="N > 1 -- weak (default): spp x N, so every GPU keeps the 1-GPU number of pixel-samples; "
+                         "strong: the fixed frame is split N ways")
+    ap.add_argument("--windows", type=int, default=7, help="timed windows of --steps steps each; value = the median window")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time (0 = skip)")
     ap.add_argument("--extras", type=int, default=1, help="0: skip the extra fields (second camera, 1-GPU reference, weak variant)")
     ap.add_argument("--save-png", default="")
@@ -144,7 +153,7 @@ def main():
     from ezrt_amd import scene as S, scenes, tiles, trace
     hip = trace.hip()  # after torch: shares torch's HIP runtime (same soname)
 
-    wl = args.workload if args.workload != "auto" else ("c2" if world == 1 else "c4")
+    wl = args.workload if args.workload != "auto" else "c2"
     cfg = dict(scenes.CONFIGS["C2" if wl == "c2" else "C4"])
     for k_arg, k_cfg in (("width", "width"), ("height", "height"), ("spp", "spp"), ("integrator", "integrator")):
         if getattr(args, k_arg):
@@ -176,71 +185,113 @@ def main():
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     plan = tiles.TilePlan(W, H, args.tile, args.tile, world) if world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
+    tdev = dev if backend == "nccl" else "cpu"
 
     gather_ev = []
 
-    def step():
-        sc.render_device(p, accum.data_ptr(), stream)
-        if world > 1:
-            if rank == 0:   # (events on the launch stream, read after the timed loop: no host sync inside it)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            out_img = tiles.gather_frame(accum, plan, rank, dist, via_cpu=(backend != "nccl"), lib=hip.lib)
-            if rank == 0:
-                e1.record()
-                gather_ev.append((e0, e1))   # rank 0's render done -> frame assembled: includes waiting for the slowest rank
-            return out_img
-        return accum
+    def make_step(sc_, p_, accum_, plan_, log_gather=None):
+        def step():
+            sc_.render_device(p_, accum_.data_ptr(), stream)
+            if world > 1:
+                if rank == 0 and log_gather is not None:   # (events on the launch stream, read after the window: no host sync inside it)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                out_img = tiles.gather_frame(accum_, plan_, rank, dist, via_cpu=(backend != "nccl"), lib=hip.lib)
+                if rank == 0 and log_gather is not None:
+                    e1.record()
+                    log_gather.append((e0, e1))   # rank 0's render done -> frame assembled: includes waiting for the slowest rank
+                return out_img
+            return accum_
+        return step
 
     def barrier():
         if world > 1:
             dist.barrier()
 
+    def timed_windows(step, n_windows, n_steps):
+        """n_windows windows of exactly n_steps steps: barrier + synchronize on both sides of each, wall clock per window
+        (MAX over ranks), one stream event per step (GPU time between step starts; read after the window) and the host's
+        enqueue time per step.  Returns (window seconds after MAX over ranks, per-window per-step GPU ms, per-window
+        per-step host enqueue ms, the last frame)."""
+        wall, gpu_ms, host_ms, last = [], [], [], None
+        for _ in range(n_windows):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]
+            enq = []
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(n_steps):
+                evs[k].record()
+                h0 = time.perf_counter()
+                last = step()
+                enq.append((time.perf_counter() - h0) * 1e3)
+            evs[n_steps].record()
+            torch.cuda.synchronize()
+            barrier()
+            wall.append(time.perf_counter() - t0)
+            gpu_ms.append([evs[k].elapsed_time(evs[k + 1]) for k in range(n_steps)])
+            host_ms.append(enq)
+        wt = torch.tensor(wall, dtype=torch.float64, device=tdev)
+        if world > 1:
+            dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+        return [float(x) for x in wt], gpu_ms, host_ms, last
+
+    step = make_step(sc, p, accum, plan, gather_ev)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     sc.counters_reset()
     gather_ev.clear()
-    step_ms = []
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        final = step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    n_windows = max(1, args.windows)
+    win_s, win_gpu_ms, win_host_ms, final = timed_windows(step, n_windows, args.steps)
     gather_s = [a.elapsed_time(b) * 1e-3 for a, b in gather_ev]
-    # per-step GPU times (hipEvents on the launch stream; reading them synchronises, so this is a separate, untimed
-    # pass of the same step): median of 7 -- (all kernels, the trace launches, number of trace launches)
-    rays_timed = sc.counters()["rays"]
-    sc.set_option("launch_events", 1)   # (a timing-event pair around every trace launch: off in the timed loop above)
+    rays_timed = sc.counters()["rays"]          # over all windows (the workload is deterministic: the same rays every step)
+    # per-step GPU times with a timing-event pair around every trace launch (hipEvents on the launch stream; reading them
+    # synchronises and each record costs the stream ~5 us, so this is a separate, untimed pass of the same step):
+    # median of 7 -- (all kernels, the trace launches, number of trace launches)
+    step_ms = []
+    sc.set_option("launch_events", 1)
     for _ in range(7):
         sc.render_device(p, accum.data_ptr(), stream)
         step_ms.append(sc.last_render_ms())
+    sc.set_option("launch_events", 0)
 
-    rays_local = rays_timed
-    tdev = dev if backend == "nccl" else "cpu"
-    tt = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=tdev)
+    tt = torch.tensor([float(rays_timed)], dtype=torch.float64, device=tdev)
     rank_ms = torch.tensor([statistics.median(m[0] for m in step_ms)], dtype=torch.float64, device=tdev)
     all_rank_ms = [float(rank_ms[0])]
     if world > 1:
-        tmax = tt.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0])
         bufs = [torch.zeros_like(rank_ms) for _ in range(world)]
         dist.all_gather(bufs, rank_ms)
         all_rank_ms = [float(b[0]) for b in bufs]
-    rays_total = float(tt[1])
-    rays_per_step = rays_total / max(1, args.steps)
-    value = rays_total / elapsed / 1e6
+    rays_per_step = float(tt[0]) / max(1, args.steps * n_windows)
+    order = sorted(range(n_windows), key=lambda i: win_s[i])
+    i_med, i_slow = order[(n_windows - 1) // 2], order[-1]      # (lower median for an even count)
+    elapsed = win_s[i_med]                                      # the median window: K steps, MAX over ranks
+    value = rays_per_step * args.steps / elapsed / 1e6
+    ms_per_step = elapsed / max(1, args.steps) * 1e3
+    gpu_step_med = statistics.median(x for w in win_gpu_ms for x in w)   # this rank's stream events, all windows
+    timing = {
+        "protocol": "%d warm-up steps, then %d windows of exactly %d steps, barrier + synchronize around each, MAX over ranks; "
+                    "value = median window" % (args.warmup, n_windows, args.steps),
+        "window_ms": [round(x * 1e3, 3) for x in win_s],
+        "window_ms_min_median_max": [round(win_s[order[0]] * 1e3, 3), round(elapsed * 1e3, 3), round(win_s[i_slow] * 1e3, 3)],
+        "first_window_Mrays_s": round(rays_per_step * args.steps / win_s[0] / 1e6, 2),
+        "gpu_ms_per_step_median_in_windows": round(gpu_step_med, 4),
+        "wall_over_gpu": round(ms_per_step / gpu_step_med, 4) if gpu_step_med > 0 else None,
+        "slowest_window": {"index": i_slow, "gpu_ms_per_step": [round(x, 3) for x in win_gpu_ms[i_slow]],
+                           "host_enqueue_ms_per_step": [round(x, 3) for x in win_host_ms[i_slow]]},
+        "first_window_gpu_ms_per_step": [round(x, 3) for x in win_gpu_ms[0]],
+    }
+    if timing["wall_over_gpu"] and timing["wall_over_gpu"] > 1.1:
+        timing["flag"] = "wall time of the median window is more than 1.1x the GPU time between step starts: host-side stall"
 
+    bounce_txt = "%d bounces" % mb
     out = {
-        "metric": "Mrays/s at fixed spp (Bunny ~70k tris, 4 bounces)",
+        "metric": "Mrays/s at fixed spp (Bunny ~70k tris, %s)" % bounce_txt,
         "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 4), "higher_is_better": True,
-        "scaling": "weak" if (weak or world == 1) else "strong",
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "n/a" if world == 1 else ("weak" if weak else "strong"),
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s (%d tris, %d BVH nodes, SAH leaf 8), %dx%d, camera rot %g up %g r %g, integrator %d, %d bounces, "
                                "%d spp%s, env = %s"
@@ -251,6 +302,7 @@ def main():
                    "parallelism": "tiles%dx%d round-robin over %d GPU(s), 1 RCCL gather/frame" % (args.tile, args.tile, world),
                    "scene_build_s": round(t_build, 3),
                    "median_gpu_ms_per_step": round(statistics.median(m[0] for m in step_ms), 4)},
+        "timing": timing,
     }
 
     if world > 1:
@@ -258,7 +310,9 @@ def main():
         mg = {"tiles_total": plan.n_tiles, "tiles_per_rank": [len(range(r, plan.n_tiles, world)) for r in range(world)],
               "render_ms_per_rank_median": [round(x, 4) for x in all_rank_ms],
               "imbalance_max_over_mean": round(max(all_rank_ms) / (sum(all_rank_ms) / world), 4),
-              "payload_bytes_per_peer": plan.per_rank * args.tile * args.tile * 16}
+              "payload_bytes_per_peer": plan.per_rank * args.tile * args.tile * 16,
+              "transport": "torch.distributed gather on the %s backend (nccl = RCCL: one grouped send/recv, peers -> rank 0), "
+                           "pack / un-permute by the library's kernels" % backend}
         if rank == 0 and gather_s:
             mg["gather_ms_median_incl_wait_for_slowest_rank"] = round(statistics.median(gather_s) * 1e3, 4)
         if args.extras:
@@ -276,37 +330,55 @@ def main():
                 d1 = time.perf_counter() - t1
                 r1 = sc.counters()["rays"] / 2
                 mg["one_gpu_same_frame"] = {"ms": round(d1 * 1e3, 3), "Mrays_s": round(r1 / d1 / 1e6, 2),
-                                            "speedup_of_this_line": round((elapsed / args.steps) and d1 / (elapsed / args.steps), 3),
+                                            "speedup_of_this_line": round(d1 / elapsed * args.steps, 3) if elapsed > 0 else None,
                                             # (a sample of chapter 5's estimator can be non-finite -- 0/0 in the MIS weights, as in the
                                             # reference -- so the comparison is on the bits, and the L-inf over the finite pixels)
-                                            "bit_identical_to_n_gpu_frame": bool(torch.equal(one.view(torch.int32), final.view(torch.int32))) if not weak else None,
-                                            "linf_vs_n_gpu_frame": float(torch.nan_to_num(one - final, nan=0.0, posinf=0.0, neginf=0.0).abs().max()) if not weak else None,
+                                            "bit_identical_to_n_gpu_frame": bool(torch.equal(one.view(torch.int32), final.view(torch.int32))),
+                                            "linf_vs_n_gpu_frame": float(torch.nan_to_num(one - final, nan=0.0, posinf=0.0, neginf=0.0).abs().max()),
                                             "non_finite_pixels": int((~torch.isfinite(one[..., :3]).all(dim=2)).sum())}
             barrier()
-            if not weak:
-                # the weak-scaling variant of the same line: spp x N, so every GPU keeps the 1-GPU number of pixel-samples
-                # (the frame is then a different, N times deeper one: an extra field, never `value`)
-                pw = params((rank, world), n_spp=cfg["spp"] * world)
-                sc.set_option("launch_events", 0)
-                wacc = torch.zeros_like(accum)
-                def wstep():
-                    sc.render_device(pw, wacc.data_ptr(), stream)
-                    tiles.gather_frame(wacc, plan, rank, dist, via_cpu=(backend != "nccl"), lib=hip.lib)
-                wstep()
+            # BASELINE.json configs[3] as a fixed frame split N ways (strong scaling): an extra field, never `value`
+            c4 = dict(scenes.CONFIGS["C4"])
+            if args.spp:
+                c4["spp"] = args.spp
+            if args.width and args.height:
+                c4["width"], c4["height"] = args.width, args.height
+            bs4 = scenes.p5_scene(subdiv=args.subdiv, hdr=args.env)
+            sc4 = bs4.upload(hip)
+            e4, cam4 = S.camera(*c4["camera"])
+            W4, H4 = c4["width"], c4["height"]
+            p4 = trace.make_params(W4, H4, e4, cam4, c4["integrator"], c4["max_bounce"], spp=c4["spp"], tile=(args.tile, args.tile),
+                                   shard=(rank, world))
+            acc4 = torch.zeros((H4, W4, 4), dtype=torch.float32, device=dev)
+            plan4 = tiles.TilePlan(W4, H4, args.tile, args.tile, world)
+            step4 = make_step(sc4, p4, acc4, plan4)
+            step4()
+            torch.cuda.synchronize()
+            sc4.counters_reset()
+            w4, _, _, fin4 = timed_windows(step4, 3, 2)
+            r4 = torch.tensor([float(sc4.counters()["rays"])], dtype=torch.float64, device=tdev)
+            dist.all_reduce(r4, op=dist.ReduceOp.SUM)
+            med4 = sorted(w4)[1]
+            c4v = {"workload": "C4: P5 scene, integrator %d, %d bounces, %dx%d, %d spp, fixed frame split over %d GPUs"
+                               % (c4["integrator"], c4["max_bounce"], W4, H4, c4["spp"], world),
+                   "scaling": "strong", "ms_per_step": round(med4 / 2 * 1e3, 3), "window_ms": [round(x * 1e3, 3) for x in w4],
+                   "Mrays_s": round(float(r4[0]) / 6 / (med4 / 2) / 1e6, 2)}
+            barrier()
+            if rank == 0:
+                one4 = torch.zeros_like(acc4)
+                p41 = trace.make_params(W4, H4, e4, cam4, c4["integrator"], c4["max_bounce"], spp=c4["spp"], tile=(args.tile, args.tile))
+                sc4.render_device(p41, one4.data_ptr(), stream)
                 torch.cuda.synchronize()
-                sc.counters_reset()
-                barrier()
-                tw = time.perf_counter()
-                for _ in range(2):
-                    wstep()
+                sc4.counters_reset()
+                t1 = time.perf_counter()
+                sc4.render_device(p41, one4.data_ptr(), stream)
                 torch.cuda.synchronize()
-                barrier()
-                wt = torch.tensor([time.perf_counter() - tw, float(sc.counters()["rays"])], dtype=torch.float64, device=tdev)
-                wmax = wt.clone()
-                dist.all_reduce(wmax, op=dist.ReduceOp.MAX)
-                dist.all_reduce(wt, op=dist.ReduceOp.SUM)
-                mg["weak_variant"] = {"spp": cfg["spp"] * world, "ms_per_step": round(float(wmax[0]) / 2 * 1e3, 3),
-                                      "Mrays_s": round(float(wt[1]) / float(wmax[0]) / 1e6, 2)}
+                d41 = time.perf_counter() - t1
+                c4v["one_gpu_same_frame"] = {"ms": round(d41 * 1e3, 3), "Mrays_s": round(sc4.counters()["rays"] / d41 / 1e6, 2),
+                                             "speedup": round(d41 / (med4 / 2), 3),
+                                             "bit_identical_to_n_gpu_frame": bool(torch.equal(one4.view(torch.int32), fin4.view(torch.int32)))}
+            barrier()
+            mg["c4_strong_variant"] = c4v
         out["multi_gpu"] = mg
 
     if rank == 0 and world == 1:

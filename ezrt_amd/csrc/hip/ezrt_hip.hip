@@ -521,27 +521,33 @@ void launch_shade_i(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
   else launch_shade_is<INTEG, 2>(a, full, grid, st);
 }
 // `between` (or NULL): an event the second pass waits for -- the stage's redo launch on the side stream
+// Returns the status of the cross-stream wait: if it failed, the second pass was NOT launched (it would read hit records
+// the redo launch is still writing) and the caller fails the render call.
 template <int INTEG, int STAGE>
-void launch_shade_split_ib(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st, hipEvent_t between) {
+hipError_t launch_shade_split_ib(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st, hipEvent_t between) {
   if (full) hipLaunchKernelGGL((shade_miss_kernel<INTEG, true, STAGE>), grid, dim3(SHADE_BLOCK), 0, st, a);
   else hipLaunchKernelGGL((shade_miss_kernel<INTEG, false, STAGE>), grid, dim3(SHADE_BLOCK), 0, st, a);
-  if (between) (void)hipStreamWaitEvent(st, between, 0);
+  if (between) {
+    const hipError_t e = hipStreamWaitEvent(st, between, 0);
+    if (e != hipSuccess) return e;
+  }
   if (full) hipLaunchKernelGGL((shade_hit_kernel<INTEG, true, STAGE>), grid_hit, dim3(SHADE_BLOCK), 0, st, a);
   else hipLaunchKernelGGL((shade_hit_kernel<INTEG, false, STAGE>), grid_hit, dim3(SHADE_BLOCK), 0, st, a);
+  return hipSuccess;
 }
 template <int INTEG>
-void launch_shade_split_i(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st, hipEvent_t between) {
-  if (a.bounce == 0) launch_shade_split_ib<INTEG, 0>(a, full, grid, grid_hit, st, between);
-  else if (a.bounce == 1) launch_shade_split_ib<INTEG, 1>(a, full, grid, grid_hit, st, between);
-  else launch_shade_split_ib<INTEG, 2>(a, full, grid, grid_hit, st, between);
+hipError_t launch_shade_split_i(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st, hipEvent_t between) {
+  if (a.bounce == 0) return launch_shade_split_ib<INTEG, 0>(a, full, grid, grid_hit, st, between);
+  if (a.bounce == 1) return launch_shade_split_ib<INTEG, 1>(a, full, grid, grid_hit, st, between);
+  return launch_shade_split_ib<INTEG, 2>(a, full, grid, grid_hit, st, between);
 }
-void launch_shade_split(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st, hipEvent_t between) {
+hipError_t launch_shade_split(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st, hipEvent_t between) {
   switch (a.p.integrator) {
-    case EZRT_INTEGRATOR_P3_DIFFUSE: launch_shade_split_i<EZRT_INTEGRATOR_P3_DIFFUSE>(a, full, grid, grid_hit, st, between); break;
-    case EZRT_INTEGRATOR_P4_DISNEY: launch_shade_split_i<EZRT_INTEGRATOR_P4_DISNEY>(a, full, grid, grid_hit, st, between); break;
-    case EZRT_INTEGRATOR_P5_SOBOL: launch_shade_split_i<EZRT_INTEGRATOR_P5_SOBOL>(a, full, grid, grid_hit, st, between); break;
-    case EZRT_INTEGRATOR_P5_MIS_ANISO: launch_shade_split_i<EZRT_INTEGRATOR_P5_MIS_ANISO>(a, full, grid, grid_hit, st, between); break;
-    default: launch_shade_split_i<EZRT_INTEGRATOR_P5_MIS>(a, full, grid, grid_hit, st, between); break;
+    case EZRT_INTEGRATOR_P3_DIFFUSE: return launch_shade_split_i<EZRT_INTEGRATOR_P3_DIFFUSE>(a, full, grid, grid_hit, st, between);
+    case EZRT_INTEGRATOR_P4_DISNEY: return launch_shade_split_i<EZRT_INTEGRATOR_P4_DISNEY>(a, full, grid, grid_hit, st, between);
+    case EZRT_INTEGRATOR_P5_SOBOL: return launch_shade_split_i<EZRT_INTEGRATOR_P5_SOBOL>(a, full, grid, grid_hit, st, between);
+    case EZRT_INTEGRATOR_P5_MIS_ANISO: return launch_shade_split_i<EZRT_INTEGRATOR_P5_MIS_ANISO>(a, full, grid, grid_hit, st, between);
+    default: return launch_shade_split_i<EZRT_INTEGRATOR_P5_MIS>(a, full, grid, grid_hit, st, between);
   }
 }
 void launch_shade(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
@@ -581,6 +587,20 @@ hipError_t ensure_chunk_scratch(EzrtScene* s, Pipe& pp, size_t n_slots, bool mis
   EZ_ENSURE(pp.defer_count.ensure(2048u * 1024u / SHADE_BLOCK));
 #undef EZ_ENSURE
   return hipSuccess;
+}
+
+void release_chunk_scratch(Pipe& pp) {
+  pp.samples.release();
+  for (int k = 0; k < 2; k++) {
+    pp.rq_o[k].release();
+    pp.rq_d[k].release();
+    for (auto& b : pp.st[k]) b.release();
+    pp.hits2[k].release();
+  }
+  pp.redo_slots.release();
+  pp.redo_flag.release();
+  pp.defer_list.release();
+  pp.defer_count.release();
 }
 
 struct PathLogTarget { // ezrt_render_paths through the timed pipeline (audit_via_queue)
@@ -860,7 +880,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     a.bounce = b;
     a.defer_list = pp.defer_list.p;
     a.defer_count = pp.defer_count.p;
-    if (split_here) launch_shade_split(a, full, dim3(shade_grid), dim3(shade_grid), st, ev_between);
+    if (split_here) HIP_TRY(launch_shade_split(a, full, dim3(shade_grid), dim3(shade_grid), st, ev_between));
     else launch_shade(a, full, dim3(shade_grid), st);
     if (debug_stages) { // diagnostic only: per-stage queue sizes and counters (synchronises)
       uint32_t q[2] = {0, 0};
@@ -1062,6 +1082,19 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
     std::vector<HostNode> hn((size_t)n_nodes);
     for (int i = 1; i < n_nodes; i++) hn[(size_t)i] = decode_node(nodes, i);
     bool nested = inner_id[1] >= 0;
+    // caller arrays may be a DAG (an inner node referenced by several parents: validation only asks parent < child).
+    // The collapse below makes one record per (parent, inner child) visit and indexes records by node, so a shared
+    // node would get two records, one of them never numbered (a write before the vector's buffer) and
+    // chains of shared nodes would multiply records.  Such arrays keep the binary kernel.
+    {
+      std::vector<unsigned char> n_parents((size_t)n_nodes, 0);
+      for (int i = 1; i < n_nodes && nested; i++) {
+        if (inner_id[(size_t)i] < 0) continue;
+        const int kids[2] = {hn[(size_t)i].left, hn[(size_t)i].right};
+        for (int k : kids)
+          if (inner_id[(size_t)k] >= 0 && ++n_parents[(size_t)k] > 1) nested = false;
+      }
+    }
     for (int i = 2; i < n_nodes && nested; i++) { // (the root's own box is never tested)
       if (inner_id[(size_t)i] < 0) continue;
       const HostNode& c = hn[(size_t)i];
@@ -1168,6 +1201,7 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
           }
           memcpy(&v[6][k], &rf, 4);
         }
+        if (number[q] < 0) return fail(EZRT_ERR_INVALID, "internal: 4-wide record %zu of node %d was never numbered", q, r.node);
         float4* o = &inner4[(size_t)number[q] * N4_FLOAT4];
         for (int c = 0; c < 3; c++) { // rows: see EZRT_SLAB_SELECT in ezrt_traceq4.h
           o[N4_ROW_AA + c] = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
@@ -1418,6 +1452,10 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
         (void)hipGetLastError();
         if (e != hipErrorOutOfMemory || chunk <= 1)
           return fail(EZRT_ERR_DEVICE, "render scratch for %zu pixel-samples in flight: %s", per_frame * chunk, hipGetErrorString(e));
+        // DevBuf::ensure never shrinks: the buffers that did fit at the failed size would stay allocated and the smaller
+        // request could fail where a clean allocation fits -- give everything back first
+        HIP_TRY(hipStreamSynchronize(st));
+        for (Pipe& q : s->pipe) release_chunk_scratch(q);
         chunk = (chunk + 1) / 2;
       }
     }
@@ -1488,7 +1526,7 @@ int ezrt_render(EzrtScene* s, const EzrtRenderParams* p, float* accum) {
   HIP_TRY(hipMemcpy(s->accum_tmp.p, accum, n * sizeof(float4), hipMemcpyHostToDevice));
   rc = ezrt_render_device(s, p, reinterpret_cast<float*>(s->accum_tmp.p), nullptr);
   if (rc) return rc;
-  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipStreamSynchronize(nullptr)); // the call's stream (side-stream launches are joined to it by events), not the device
   HIP_TRY(hipMemcpy(accum, s->accum_tmp.p, n * sizeof(float4), hipMemcpyDeviceToHost));
   return 0;
 }
@@ -1511,17 +1549,31 @@ int ezrt_frame_destroy(float* frame_dev) {
   if (frame_dev) HIP_TRY(hipFree(frame_dev));
   return 0;
 }
+// Synchronise the device that OWNS the frame (whatever stream rendered into it), not whichever device happens to be
+// current: the frame may have been created and rendered while another device was current (ezrt_mgpu, a host that
+// switches devices).  The caller's current device is restored on every exit.
+static int frame_copy(float* frame_dev, float* rgba_host, size_t bytes, bool to_host) {
+  hipPointerAttribute_t at;
+  HIP_TRY(hipPointerGetAttributes(&at, frame_dev));
+  int prev = 0;
+  HIP_TRY(hipGetDevice(&prev));
+  struct Restore {
+    int d;
+    ~Restore() { (void)hipSetDevice(d); }
+  } restore{prev};
+  if (at.device != prev) HIP_TRY(hipSetDevice(at.device));
+  HIP_TRY(hipDeviceSynchronize());
+  if (to_host) HIP_TRY(hipMemcpy(rgba_host, frame_dev, bytes, hipMemcpyDeviceToHost));
+  else HIP_TRY(hipMemcpy(frame_dev, rgba_host, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
 int ezrt_frame_read(const float* frame_dev, int width, int height, float* rgba_host) {
   if (!frame_dev || !rgba_host || width <= 0 || height <= 0) return fail(EZRT_ERR_INVALID, "bad frame arguments");
-  HIP_TRY(hipDeviceSynchronize()); // whatever stream rendered into it
-  HIP_TRY(hipMemcpy(rgba_host, frame_dev, (size_t)width * height * sizeof(float4), hipMemcpyDeviceToHost));
-  return 0;
+  return frame_copy(const_cast<float*>(frame_dev), rgba_host, (size_t)width * height * sizeof(float4), true);
 }
 int ezrt_frame_write(float* frame_dev, int width, int height, const float* rgba_host) {
   if (!frame_dev || !rgba_host || width <= 0 || height <= 0) return fail(EZRT_ERR_INVALID, "bad frame arguments");
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(frame_dev, rgba_host, (size_t)width * height * sizeof(float4), hipMemcpyHostToDevice));
-  return 0;
+  return frame_copy(frame_dev, const_cast<float*>(rgba_host), (size_t)width * height * sizeof(float4), false);
 }
 
 int ezrt_render_paths(EzrtScene* s, const EzrtRenderParams* p, int32_t* tri_id, float* t_hit, float* colour) {

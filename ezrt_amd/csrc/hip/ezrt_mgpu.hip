@@ -90,6 +90,30 @@ __global__ void unpack_tiles_kernel(const float4* packed, EzrtTilePlan plan, int
   if (ezrt_tiles_packed_to_pixel(&plan, rank, k, &x, &y)) accum[(size_t)y * plan.width + x] = packed[k];
 }
 
+// Error paths return from the middle of a multi-device sequence (MG_TRY / NCCL_TRY): these guards put the process back
+// into a consistent state on every exit -- the caller's current device restored, an open RCCL group closed (an open
+// group would swallow every later collective of the process, torch's included).
+struct DeviceRestore {
+  int prev = 0;
+  DeviceRestore() { (void)hipGetDevice(&prev); }
+  ~DeviceRestore() { (void)hipSetDevice(prev); }
+};
+struct RcclGroup {
+  bool open = false;
+  int start() {
+    const int e = g_rccl.GroupStart();
+    open = e == 0;
+    return e;
+  }
+  int end() {
+    open = false;
+    return g_rccl.GroupEnd();
+  }
+  ~RcclGroup() {
+    if (open) (void)g_rccl.GroupEnd();
+  }
+};
+
 struct Replica {
   int dev = 0;
   EzrtScene* sc = nullptr;
@@ -262,16 +286,19 @@ int ezrt_mgpu_render(EzrtMgpu* m, const EzrtRenderParams* p) {
   if (!m || !p) return mfail(EZRT_ERR_INVALID, "NULL argument");
   if (p->width <= 0 || p->height <= 0) return mfail(EZRT_ERR_INVALID, "width/height must be positive");
   const int n = (int)m->r.size();
-  int prev = 0;
-  (void)hipGetDevice(&prev);
+  DeviceRestore restore;
   if (p->width != m->width || p->height != m->height) { // new frame size: empty shards
     int rc = release_frames(m);
     if (rc) return rc;
     const size_t texels = (size_t)p->width * p->height;
     for (Replica& q : m->r) {
-      MG_TRY(hipSetDevice(q.dev));
-      MG_TRY(hipMalloc((void**)&q.accum, texels * sizeof(float4)));
-      MG_TRY(hipMemsetAsync(q.accum, 0, texels * sizeof(float4), q.st));
+      hipError_t e = hipSetDevice(q.dev);
+      if (e == hipSuccess) e = hipMalloc((void**)&q.accum, texels * sizeof(float4));
+      if (e == hipSuccess) e = hipMemsetAsync(q.accum, 0, texels * sizeof(float4), q.st);
+      if (e != hipSuccess) { // all replicas or none: a half-allocated set would pass the size test of the next call
+        (void)release_frames(m);
+        return mfail(EZRT_ERR_DEVICE, std::string("frame buffers of the replicas: ") + hipGetErrorString(e));
+      }
     }
     m->width = p->width;
     m->height = p->height;
@@ -289,7 +316,6 @@ int ezrt_mgpu_render(EzrtMgpu* m, const EzrtRenderParams* p) {
     MG_TRY(hipEventRecord(q.e1, q.st));
     q.rendered = true;
   }
-  (void)hipSetDevice(prev);
   if (rc) return rc;
   m->last = *p;
   m->have_last = true;
@@ -300,8 +326,7 @@ int ezrt_mgpu_gather(EzrtMgpu* m, float* accum_rgba) {
   if (!m) return mfail(EZRT_ERR_INVALID, "NULL argument");
   if (!m->have_last) return mfail(EZRT_ERR_INVALID, "ezrt_mgpu_gather before any ezrt_mgpu_render");
   const int n = (int)m->r.size();
-  int prev = 0;
-  (void)hipGetDevice(&prev);
+  DeviceRestore restore;
   const EzrtTilePlan plan = ezrt_tile_plan(m->width, m->height, m->last.tile_w, m->last.tile_h, n);
   // the renders first: their time is theirs, the gather's is measured from here
   for (Replica& q : m->r) {
@@ -345,7 +370,8 @@ int ezrt_mgpu_gather(EzrtMgpu* m, float* accum_rgba) {
   }
   // 2. the shards travel to the root: ONE grouped exchange
   if (m->transport == EZRT_TRANSPORT_RCCL && n > 1) {
-    NCCL_TRY(g_rccl.GroupStart());
+    RcclGroup group; // (closed by its destructor when a send / receive below fails)
+    NCCL_TRY(group.start());
     size_t off = 0;
     for (int i = 1; i < n; i++) {
       Replica& q = m->r[(size_t)i];
@@ -356,7 +382,7 @@ int ezrt_mgpu_gather(EzrtMgpu* m, float* accum_rgba) {
       }
       off += cnt;
     }
-    NCCL_TRY(g_rccl.GroupEnd());
+    NCCL_TRY(group.end());
   } else {
     MG_TRY(hipSetDevice(root.dev));
     size_t off = 0;
@@ -398,7 +424,6 @@ int ezrt_mgpu_gather(EzrtMgpu* m, float* accum_rgba) {
   MG_TRY(hipSetDevice(root.dev));
   MG_TRY(hipEventElapsedTime(&m->gather_ms, m->g0, m->g1));
   m->gather_bytes = (int64_t)(total * sizeof(float4));
-  (void)hipSetDevice(prev);
   return 0;
 }
 
@@ -411,20 +436,15 @@ int ezrt_mgpu_frame_device(EzrtMgpu* m, float** frame_dev) {
 
 int ezrt_mgpu_counters(EzrtMgpu* m, uint64_t out[EZRT_CTR_COUNT]) {
   if (!m || !out) return mfail(EZRT_ERR_INVALID, "NULL argument");
-  int prev = 0;
-  (void)hipGetDevice(&prev);
+  DeviceRestore restore;
   for (int k = 0; k < EZRT_CTR_COUNT; k++) out[k] = 0;
   for (Replica& q : m->r) {
     uint64_t c[EZRT_CTR_COUNT];
     MG_TRY(hipSetDevice(q.dev));
     int rc = ezrt_counters(q.sc, c);
-    if (rc) {
-      (void)hipSetDevice(prev);
-      return rc;
-    }
+    if (rc) return rc;
     for (int k = 0; k < EZRT_CTR_COUNT; k++) out[k] += c[k];
   }
-  (void)hipSetDevice(prev);
   return 0;
 }
 

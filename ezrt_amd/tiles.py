@@ -83,20 +83,28 @@ def _gather_frame_native(accum, plan, rank, dist, dst, lib, via_cpu=False):
     st = torch.cuda.current_stream(accum.device).cuda_stream if accum.is_cuda else None
     args = (plan.width, plan.height, plan.tile_w, plan.tile_h)
     n = plan.per_rank * plan.tile_h * plan.tile_w * 4   # equal-size payloads for the collective (<= one tile of padding)
-    packed = torch.zeros(n, dtype=torch.float32, device=accum.device)
+    # payload and receive buffers live with the plan (allocated on first use, zeroed once: the pack kernel rewrites every
+    # real entry on each call, the padding is never read by the un-permute kernel) -- nothing is allocated per frame
+    key = ("native", str(accum.device), bool(via_cpu), rank == dst)
+    if key not in plan._ids:
+        packed = torch.zeros(n, dtype=torch.float32, device=accum.device)
+        wire = torch.zeros(n, dtype=torch.float32, pin_memory=accum.is_cuda) if via_cpu else packed
+        bufs = [torch.zeros_like(wire) for _ in range(plan.world)] if rank == dst else None
+        plan._ids[key] = (packed, wire, bufs)
+    packed, wire, bufs = plan._ids[key]
     if lib.ezrt_tiles_pack_device(accum.data_ptr(), *args, rank, plan.world, packed.data_ptr(), st) != 0:
         raise RuntimeError(lib.ezrt_last_error().decode())
     if via_cpu:
-        packed = packed.cpu()
+        wire.copy_(packed)   # (synchronises: host staging is the gloo debugging route only)
     if rank != dst:
-        dist.gather(packed, gather_list=None, dst=dst)
+        dist.gather(wire, gather_list=None, dst=dst)
         return accum
-    bufs = [torch.empty_like(packed) for _ in range(plan.world)]
-    dist.gather(packed, gather_list=bufs, dst=dst)
-    if via_cpu:
-        bufs = [b.to(accum.device) for b in bufs]
+    dist.gather(wire, gather_list=bufs, dst=dst)
     for r in range(plan.world):
-        if r != dst and lib.ezrt_tiles_unpack_device(bufs[r].data_ptr(), *args, r, plan.world, accum.data_ptr(), st) != 0:
+        if r == dst:
+            continue
+        src = bufs[r].to(accum.device) if via_cpu else bufs[r]
+        if lib.ezrt_tiles_unpack_device(src.data_ptr(), *args, r, plan.world, accum.data_ptr(), st) != 0:
             raise RuntimeError(lib.ezrt_last_error().decode())
     return accum
 

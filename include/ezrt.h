@@ -21,6 +21,14 @@
  * The same ABI is implemented twice: libezrt_hip.so (hand-written gfx950 HIP
  * kernels -- the product) and oracle/libezrt_oracle.so (plain-C restatement of
  * the reference arithmetic -- test infrastructure only).
+ *
+ * Numerical contract: every finite value is reproduced on the bits (triangle
+ * ids, distances, radiance, the running mean).  NOT part of the contract: the
+ * sign and payload of a NaN.  Chapter 5's estimator can evaluate 0/0 in its MIS
+ * weights (P5/fsh:754-757 with both pdfs 0 -- the reference does the same); such a
+ * sample poisons its pixel's running mean, and the pixel is NaN in both
+ * implementations, but x86 and gfx950 produce different quiet NaNs (0x7fc00000 /
+ * 0xffc00000).  Compare frames with NaN == NaN (tests/: `_same_bits_or_both_nan`).
  */
 #ifndef EZRT_H
 #define EZRT_H

@@ -327,6 +327,44 @@ def test_boxes_that_are_not_nested_fall_back_to_the_binary_kernel(hip, oracle, b
     assert np.array_equal(tg, to) and np.array_equal(_bits(dg), _bits(do))
 
 
+def test_node_arrays_that_are_a_dag_keep_the_binary_kernel(hip, oracle, bunny_small):
+    """Caller arrays may reference an inner node from several parents (validation only asks parent < child).  The
+    4-wide collapse indexes its records by node, so such arrays must not reach it (a shared inner node got
+    two records, one never numbered -> a write before the record vector's buffer, and chains of shared nodes multiplied
+    records).  Here: 200 inner nodes get their RIGHT child replaced by a later inner node that already has a parent --
+    still parent < child, boxes enlarged so that they stay nested -- and the frame must be the reference's."""
+    nodes = bunny_small.nodes.copy()
+    n = nodes.shape[0]
+    is_inner = nodes[:, 3] == 0
+    is_inner[:2] = False
+    rng = np.random.default_rng(11)
+    cand = [i for i in np.nonzero(is_inner)[0] if is_inner[int(nodes[i, 1])]]
+    parents = rng.choice(cand, 200, replace=False)
+    inner_ids = np.nonzero(is_inner)[0]
+    for i in parents:
+        later = inner_ids[inner_ids > max(int(nodes[i, 0]), int(nodes[i, 1]))]
+        if later.size == 0:
+            continue
+        nodes[i, 1] = np.float32(rng.choice(later))
+    # make every box contain its children's again (ids are topologically ordered: one backwards pass)
+    for i in range(n - 1, 0, -1):
+        if nodes[i, 3] == 0:
+            for c in (int(nodes[i, 0]), int(nodes[i, 1])):
+                nodes[i, 6:9] = np.minimum(nodes[i, 6:9], nodes[c, 6:9])
+                nodes[i, 9:12] = np.maximum(nodes[i, 9:12], nodes[c, 9:12])
+    sg, so = hip.scene_create(bunny_small.tri, nodes), oracle.scene_create(bunny_small.tri, nodes)
+    hdr = scenes.synthetic_hdr(64, 32)
+    sg.set_env(hdr, None, 1)
+    so.set_env(hdr, None, 1)
+    eye, cam = S.camera(10, 5, 3)
+    p = trace.make_params(96, 80, eye, cam, 50, 3, spp=2)
+    assert np.array_equal(_bits(sg.render(p)), _bits(so.render(p)))
+    sg.set_instrumentation(1)
+    so.set_instrumentation(1)
+    sg.render(p), so.render(p)
+    assert sg.counters() == so.counters()
+
+
 def test_deep_skewed_tree_uses_many_stack_rows(hip, oracle):
     """A median-split tree with leaf size 1 over a thin strip of triangles: depth 12+, every ray
     walks long chains; exercises the LDS stack rows and the leaf encoding with n = 1."""
