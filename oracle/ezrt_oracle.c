@@ -6,17 +6,23 @@
  * this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
  * leg do.
  *
- * PARITY PINNING STATUS.  The reference (a GLSL fragment shader + GLUT host,
- * no tests) cannot be compiled or run here (no GLM/GLEW/GL context; SURVEY.md
- * 8c).  What the reference pins and this oracle is checked against:
- *   - the 30x3 Sobol known-answer table of T5 (tests/golden/sobol_kat.json),
- *   - the testNode int<->float round trip (P3/main.cpp:707-713),
- *   - "BVH result == brute force" (P2/main.cpp:585) as a property.
- * Everything else -- GLSL built-in precision, GLM evaluation order, bilinear
- * weights -- is implementation-defined in the reference: PARITY UNPINNED.
- * For those this file *is* the specification: fp32 everywhere, fixed
- * left-to-right evaluation order, transcendental built-ins from
- * include/ezrt_detmath.h, min/max as (b<a)?b:a / (a<b)?b:a.
+ * PARITY PINNING STATUS: PINNED BY EXECUTION against the reference itself, compiled here from /root/reference by
+ * oracle/ref_recipe/build_ref.py into oracle/_ref/ (nothing of it is copied into the repository):
+ *   - host half (readObj, builders, encode, HDRLoader, calculateHdrCache, camera, the C++ twins of hitTriangle /
+ *     hitAABB, chapter 2's probe ray): P2..P5 main.cpp + lib/hdrloader.cpp against GLM/GL stand-ins
+ *     (tests/test_ref_pin.py, tests/test_gpu_ref_pin.py);
+ *   - SHADER half (this file's restatement of P5/fsh:160-890, P4/fsh:412-517, P3/fsh:376-413): the three
+ *     `shaders/fshader.fsh` themselves, compiled by g++ through a syntax-only source pass and a GLSL language shim
+ *     (ref_recipe/fsh_pass.py, wrap_fsh.cpp, shim/glsl_shim.h): seed, BRDF_Evaluate (both chapters' forms),
+ *     SampleBRDF, BRDF_Pdf, hdrPdf, SampleHdr, hdrColor, hemisphere sampling on 10^5 random inputs each, hitBVH's
+ *     whole HitResult, and main()'s running mean per pixel and frame for the integrators 3 / 4 / 50 / 51 -- all
+ *     bit-equal (tests/test_ref_fsh_pin.py); frames of the executed shaders are frozen in tests/golden/
+ *     fsh_golden.npz and must be reproduced by this oracle AND by libezrt_hip.so (tests/test_fsh_golden.py);
+ *   - the 30x3 Sobol known-answer table of T5 (tests/golden/sobol_kat.json).
+ * What the reference leaves to the GLSL driver has nothing to be pinned against and is DEFINED here, shared by
+ * oracle, shim and kernels: the precision of sin cos atan asin log pow (include/ezrt_detmath.h), the expansion of
+ * dot / normalize / mix / reflect, min/max as (b<a)?b:a / (a<b)?b:a, texture filtering (texel centres, clamp to
+ * edge, GL's bilinear formula in fp32), fp32 everywhere with no contraction.
  *
  * Each function cites the reference lines it follows.  Shorthands:
  *   P5/fsh = part 5 .../shaders/fshader.fsh   P4/fsh, P3/fsh likewise
@@ -1172,6 +1178,103 @@ int ezrt_last_render_ms(EzrtScene* s, float* total_ms, float* trace_kernel_ms, i
 int ezrt_scene_stats(EzrtScene* s, int64_t out[6]) {
   if (!s || !out) return fail(EZRT_ERR_INVALID, "NULL argument");
   memcpy(out, s->stats, sizeof s->stats);
+  return 0;
+}
+
+/* ezrt_oracle_fn -- ORACLE-ONLY export (not part of include/ezrt.h): function-level access to the restated shader
+ * functions, so that tests/test_ref_fsh_pin.py can compare each of them with the REFERENCE'S OWN shader function compiled
+ * by oracle/ref_recipe (wrap_fsh.cpp: fsh_fn, same op numbers and layouts).  p5: the chapter whose variant is meant
+ * (5: P5 smooth-normal formula / isotropic evaluate; 4 and 3: the P3/P4 forms).
+ *   1 BRDF_Evaluate (P5/fsh:500-549)            a = n x (V N L), b = n x material18       -> n x 3
+ *   2 the uniform loop's evaluate with X, Y = getTangent(N): P4/fsh:412-473 (chapter 4, anisotropic) or
+ *     P5/fsh:437-498 BRDF_Evaluate_aniso (chapter 5, isotropic body)                      -> n x 3
+ *   3 SampleBRDF (P5/fsh:633-664)               a = n x (xi1 xi2 xi3 V N), b              -> n x 3
+ *   4 BRDF_Pdf (P5/fsh:715-752)                 a = n x (V N L), b                        -> n
+ *   5 hdrPdf (P5/fsh:701-712)                   a = n x L                                 -> n
+ *   6 SampleHdr (P5/fsh:667-679)                a = n x (xi1 xi2)                         -> n x 3
+ *   7 hdrColor / sampleHdr (P5/fsh:693-697; chapter 3 clamps to 10, P3/fsh:151-156)       -> n x 3
+ *   8 hitBVH (P5/fsh:254-306)                   a = n x (S d) -> n x 12: isHit isInside distance hitPoint normal baseColor
+ *   9 toNormalHemisphere(SampleHemisphere(xi1, xi2), N) (P5/fsh:561-576)  a = n x (xi1 xi2 N) -> n x 3 */
+int ezrt_oracle_fn(EzrtScene* s, int op, int chapter, const float* a, const float* b, int n, float* out) {
+  if (!a || !out || n < 0) return fail(EZRT_ERR_INVALID, "bad argument");
+  Ctr local;
+  memset(&local, 0, sizeof local);
+  Ctx cx;
+  cx.s = s;
+  cx.ctr = &local;
+  cx.full = 0;
+  cx.p5tri = chapter >= 5;
+  if ((op >= 5 && op <= 8) && !s) return fail(EZRT_ERR_INVALID, "this op needs a scene");
+  for (int i = 0; i < n; i++) {
+    Material m;
+    memset(&m, 0, sizeof m);
+    if (b && op >= 1 && op <= 4) {
+      const float* q = b + (size_t)i * 18;
+      m.emissive = V3(q[0], q[1], q[2]);
+      m.baseColor = V3(q[3], q[4], q[5]);
+      m.subsurface = q[6]; m.metallic = q[7]; m.specular = q[8]; m.specularTint = q[9]; m.roughness = q[10];
+      m.anisotropic = q[11]; m.sheen = q[12]; m.sheenTint = q[13]; m.clearcoat = q[14]; m.clearcoatGloss = q[15];
+      m.IOR = q[16]; m.transmission = q[17];
+    }
+    const float* p = a;
+    v3 r = V3(0, 0, 0);
+    switch (op) {
+      case 1:
+        p += (size_t)i * 9;
+        r = brdf_evaluate(V3(p[0], p[1], p[2]), V3(p[3], p[4], p[5]), V3(p[6], p[7], p[8]), V3(0, 0, 0), V3(0, 0, 0), &m, 0);
+        break;
+      case 2: {
+        p += (size_t)i * 9;
+        v3 X, Y, N = V3(p[3], p[4], p[5]);
+        get_tangent(N, &X, &Y);
+        r = brdf_evaluate(V3(p[0], p[1], p[2]), N, V3(p[6], p[7], p[8]), X, Y, &m, chapter == 4);
+        break;
+      }
+      case 3:
+        p += (size_t)i * 9;
+        r = sample_brdf(p[0], p[1], p[2], V3(p[3], p[4], p[5]), V3(p[6], p[7], p[8]), &m);
+        break;
+      case 4:
+        p += (size_t)i * 9;
+        out[i] = brdf_pdf(V3(p[0], p[1], p[2]), V3(p[3], p[4], p[5]), V3(p[6], p[7], p[8]), &m);
+        continue;
+      case 5:
+        p += (size_t)i * 3;
+        out[i] = hdr_pdf(&cx, V3(p[0], p[1], p[2]));
+        continue;
+      case 6:
+        p += (size_t)i * 2;
+        r = sample_hdr(&cx, p[0], p[1]);
+        break;
+      case 7:
+        p += (size_t)i * 3;
+        r = hdr_color(&cx, V3(p[0], p[1], p[2]), chapter == 3 ? 10.0f : 0.0f);
+        break;
+      case 8: {
+        p += (size_t)i * 6;
+        HitResult h = hit_bvh(&cx, V3(p[0], p[1], p[2]), V3(p[3], p[4], p[5]));
+        float* o = out + (size_t)i * 12;
+        for (int k = 0; k < 12; k++) o[k] = 0.0f;
+        o[0] = h.isHit ? 1.0f : 0.0f;
+        o[2] = h.distance;
+        if (h.isHit) {
+          o[1] = h.isInside ? 1.0f : 0.0f;
+          o[3] = h.hitPoint.x; o[4] = h.hitPoint.y; o[5] = h.hitPoint.z;
+          o[6] = h.normal.x; o[7] = h.normal.y; o[8] = h.normal.z;
+          o[9] = h.material.baseColor.x; o[10] = h.material.baseColor.y; o[11] = h.material.baseColor.z;
+        }
+        continue;
+      }
+      case 9:
+        p += (size_t)i * 5;
+        r = to_normal_hemisphere(sample_hemisphere(p[0], p[1]), V3(p[2], p[3], p[4]));
+        break;
+      default: return fail(EZRT_ERR_INVALID, "unknown op");
+    }
+    out[(size_t)i * 3] = r.x;
+    out[(size_t)i * 3 + 1] = r.y;
+    out[(size_t)i * 3 + 2] = r.z;
+  }
   return 0;
 }
 

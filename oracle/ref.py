@@ -240,3 +240,73 @@ class P2:
         lines = np.zeros((self.lib.ref_p2_lines_count(), 3), np.float32)
         self.lib.ref_p2_lines_get(_fp(lines))
         return lines
+
+
+# ----------------------------------------------------------------------------------------------
+# the chapters' FRAGMENT SHADERS compiled (oracle/ref_recipe/wrap_fsh.cpp, fsh_pass.py, shim/glsl_shim.h)
+def fsh_available(chapter=5):
+    return os.path.exists(os.path.join(REF_DIR, "libezrt_ref_fsh_p%d.so" % chapter))
+
+
+class Fsh:
+    """One chapter's shaders/fshader.fsh as a shared library: main() per pixel-sample, and its functions."""
+
+    OUT_WIDTH = {1: 3, 2: 3, 3: 3, 4: 1, 5: 1, 6: 3, 7: 3, 8: 12, 9: 3}
+    IN_WIDTH = {1: 9, 2: 9, 3: 9, 4: 9, 5: 3, 6: 2, 7: 3, 8: 6, 9: 5}
+
+    def __init__(self, chapter):
+        self.chapter = int(chapter)
+        L = self.lib = C.CDLL(os.path.join(REF_DIR, "libezrt_ref_fsh_p%d.so" % self.chapter))
+        L.fsh_set_scene.argtypes = [_F, C.c_int, _F, C.c_int]
+        L.fsh_set_env.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int]
+        L.fsh_set_camera.argtypes = [_F, _F, C.c_int, C.c_int]
+        L.fsh_set_integrator.argtypes = [C.c_int, C.c_int]
+        L.fsh_render.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_uint, _F]
+        L.fsh_seed.argtypes = [C.c_int, C.c_int, C.c_uint]
+        L.fsh_seed.restype = C.c_uint
+        L.fsh_fn.argtypes = [C.c_int, _F, _F, C.c_int, _F]
+        L.fsh_fn.restype = C.c_int
+        assert L.fsh_chapter() == self.chapter
+
+    def set_scene(self, tri, nodes):
+        tri = np.ascontiguousarray(tri, np.float32).reshape(-1, 36)
+        nodes = np.ascontiguousarray(nodes, np.float32).reshape(-1, 12)
+        self.lib.fsh_set_scene(_fp(tri), tri.shape[0], _fp(nodes), nodes.shape[0])
+
+    def set_env(self, hdr, cache, bilinear):
+        hdr = np.ascontiguousarray(hdr, np.float32)
+        h, w, _ = hdr.shape
+        cp = None
+        if cache is not None:
+            cache = np.ascontiguousarray(cache, np.float32)
+            cp = _fp(cache)
+        self.lib.fsh_set_env(_fp(hdr), cp, w, h, int(bilinear))
+
+    def set_camera(self, eye, camera_rotate, width, height):
+        e = np.ascontiguousarray(eye, np.float32)
+        c = np.ascontiguousarray(camera_rotate, np.float32).reshape(16)
+        self.lib.fsh_set_camera(_fp(e), _fp(c), int(width), int(height))
+        self.width, self.height = int(width), int(height)
+
+    def set_integrator(self, max_bounce, use_importance_sampling):
+        self.lib.fsh_set_integrator(int(max_bounce), int(use_importance_sampling))
+
+    def render(self, frame0, spp, accum=None, rect=None):
+        if accum is None:
+            accum = np.zeros((self.height, self.width, 4), np.float32)
+        x0, y0, x1, y1 = rect if rect is not None else (0, 0, self.width, self.height)
+        self.lib.fsh_render(x0, y0, x1, y1, int(frame0), int(spp), _fp(accum))
+        return accum
+
+    def seed(self, ix, iy, frame):
+        return int(self.lib.fsh_seed(int(ix), int(iy), int(frame)))
+
+    def fn(self, op, a, b=None):
+        a = np.ascontiguousarray(a, np.float32).reshape(-1, self.IN_WIDTH[op])
+        n = a.shape[0]
+        bb = np.ascontiguousarray(b, np.float32) if b is not None else np.zeros((n, 18), np.float32)
+        out = np.zeros((n, self.OUT_WIDTH[op]), np.float32)
+        rc = self.lib.fsh_fn(int(op), _fp(a), _fp(bb), n, _fp(out))
+        if rc != 0:
+            raise ValueError("chapter %d's shader has no op %d" % (self.chapter, op))
+        return out

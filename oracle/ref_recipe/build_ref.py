@@ -11,14 +11,19 @@ Outputs (git-ignored, but they travel to the GPU box with the snapshot):
                                     flat buildBVH/buildBVHwithSAH, main() headless, display() camera)
     oracle/_ref/libezrt_ref_p4.so   chapter 4 (Material defaults of P4/P5)
     oracle/_ref/libezrt_ref_p5.so   chapter 5 (+ calculateHdrCache)
+    oracle/_ref/libezrt_ref_fsh_p{3,4,5}.so   the chapters' FRAGMENT SHADERS (shaders/fshader.fsh) compiled by g++: the
+                                    shader text goes through the syntax-only pass of fsh_pass.py into a temporary
+                                    file that wrap_fsh.cpp #includes against shim/glsl_shim.h (the GLSL language)
 The reference's build system (CMake + GLM/GLEW/freeglut) is NOT used: each chapter is one
 main.cpp, compiled by g++ directly against the stand-in headers in oracle/ref_recipe/shim/.
 Same arithmetic contract as the rest of the repo: -O2 -ffp-contract=off -fno-fast-math.
 """
 import argparse
 import os
+import shutil
 import subprocess
 import sys
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), "_ref")
@@ -65,6 +70,38 @@ def build(ref="/root/reference", verbose=True):
         if verbose:
             print("[oracle/_ref] g++ %s <- %s" % (os.path.basename(out), main_cpp))
         subprocess.check_call(cmd)
+        built.append(out)
+    built += build_fsh(ref, verbose)
+    return built
+
+
+def build_fsh(ref, verbose=True):
+    """libezrt_ref_fsh_p{3,4,5}.so: each chapter's fragment shader, compiled (see wrap_fsh.cpp / fsh_pass.py)."""
+    sys.path.insert(0, HERE)
+    import fsh_pass
+    repo = os.path.dirname(os.path.dirname(HERE))
+    built = []
+    for ch in (3, 4, 5):
+        fsh = os.path.join(source_dir(ref, "p%d" % ch), "shaders", "fshader.fsh")
+        out = os.path.join(OUT, "libezrt_ref_fsh_p%d.so" % ch)
+        deps = [fsh, os.path.join(HERE, "wrap_fsh.cpp"), os.path.join(HERE, "fsh_pass.py"), os.path.join(HERE, "shim", "glsl_shim.h"),
+                os.path.join(repo, "include", "ezrt_detmath.h"), os.path.abspath(__file__)]
+        if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+            built.append(out)
+            continue
+        tmp = tempfile.mkdtemp(prefix="ezrt_fsh_")
+        try:
+            inc = os.path.join(tmp, "fsh_p%d.inc" % ch)
+            with open(inc, "w", encoding="utf-8") as f:
+                f.write(fsh_pass.translate(open(fsh, encoding="utf-8").read(), ch))
+            cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fno-math-errno",
+                   "-fsingle-precision-constant", "-w", "-I", os.path.join(HERE, "shim"), "-I", os.path.join(repo, "include"),
+                   '-DEZRT_REF_FSH="%s"' % inc, "-DEZRT_FSH_CHAPTER=%d" % ch, "-o", out, os.path.join(HERE, "wrap_fsh.cpp")]
+            if verbose:
+                print("[oracle/_ref] g++ %s <- %s" % (os.path.basename(out), fsh))
+            subprocess.check_call(cmd)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)   # the translated shader text is not kept anywhere
         built.append(out)
     return built
 
