@@ -66,6 +66,7 @@ TRACE_ABI = {
     "ezrt_counters_reset": (C.c_int, [C.c_void_p]),
     "ezrt_last_render_ms": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.POINTER(C.c_int)]),
     "ezrt_scene_stats": (C.c_int, [C.c_void_p, c_int64_p]),
+    "ezrt_scene_prune_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "ezrt_debug_math": (C.c_int, [C.c_int, c_float_p, c_float_p, C.c_int, c_float_p]),
     "ezrt_last_error": (C.c_char_p, []),
     "ezrt_trim": (C.c_int, []),

@@ -110,6 +110,9 @@ struct Tuning {
                            // record costs the stream ~5 us: -1.2 % on C2); 0: only the call's begin / end events
   int env_planes = 1;      // the env cache as an (x, y) plane and a pdf plane for bilinear lookups (one load per row)
   int env_rgbe = 1;        // environment lookups through the 4-byte RGBE form of the map when it has an exact one (set_env)
+  int prune = 2;           // traceq4_kernel's distance pruning (ezrt_traceq4.h "Distance pruning": proven results-neutral): 0 the
+                           // reference's unpruned traversal, 1 skip slots provably beyond the best hit, 2 that + nearest slot first
+  int prune_min_records = 0; // scenes with fewer 4-wide records than this are traced unpruned (small trees gain nothing)
   int audit_via_queue = 0; // 1: ezrt_query_hits and ezrt_render_paths run through the TIMED kernels (traceq_kernel with
                            // the template, LDS layout, stealing and redo launch of a render call + the streaming shading
                            // stages) instead of the in-order audit kernels; 2 (query only): additionally treat the rays as
@@ -148,6 +151,8 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"redo_overlap", &Tuning::redo_overlap, 0, 1},
                               {"debug_force_pending", &Tuning::debug_force_pending, 0, 1 << 20},
                               {"debug_oom_above", &Tuning::debug_oom_above, 0, 1 << 30},
+                              {"prune", &Tuning::prune, 0, 2},
+                              {"prune_min_records", &Tuning::prune_min_records, 0, 1 << 24},
                               {"audit_via_queue", &Tuning::audit_via_queue, 0, 2}};
 Tuning tuning_from_env() {
   Tuning t;
@@ -201,6 +206,15 @@ struct EzrtScene {
   DevBuf<float4> inner4;      // 4-wide records (ezrt_traceq4.h), breadth-first; empty when the boxes are not nested
   int n_inner4 = 0;
   int stack_need4 = 1;        // LDS stack rows the 4-wide traversal can need (exact worst case over hit patterns)
+  // distance pruning (ezrt_traceq4.h): scene maxima of the per-triangle bound, evaluated in double at create
+  bool prunable = false;      // every leaf box holds its triangles (and the boxes are nested: the 4-wide records exist)
+  double prune_G = 0.0;       // max 1 / sin(theta'/2) over the triangles with a bound (diagnostic)
+  double prune_Z = 0.0;       // max distance of a vertex from its triangle's stored plane (diagnostic)
+  double prune_M = 0.0;       // max |coordinate| (diagnostic)
+  float prune_a = 0.0f;       // launch argument: 2 max eta_T over the ordinary triangles, rounded up
+  double prune_A_med = 0.0;   // 2 median eta_T (diagnostic)
+  int64_t prune_bad = 0;      // triangles that are not ordinary (a large bound or none): the records above them are never pruned
+  int64_t prune_flagged = 0;  // ... how many records that is
   uint32_t root4 = 0;
   DevBuf<float4> hdr, cache;
   DevBuf<float2> cache_xy; // the cache as two planes (bilinear lookups: one load per row; knob env_planes)
@@ -424,8 +438,17 @@ void launch_traceq_cfg(EzrtScene* s, const TraceCfg& c, const TraceQArgs& q, boo
 // waves per SIMD of a traceq4 launch: the primary stage's variant may run one more (trace_wps_rel), but only while
 // that still leaves room for a useful top of the tree in LDS (deep trees need the space for stack rows: C5 and C3
 // would stage ONE record at 7 workgroups per CU and lose 3 %)
+// distance pruning of the timed stages: knob, scene property, instrumentation off
+int prune_mode(const EzrtScene* s) {
+  if (!s->prunable || s->n_inner4 < s->tune.prune_min_records) return 0;
+  return s->tune.prune;
+}
+// stack rows of a traceq4 launch: the exact worst case of the slot-order traversal; the nearest-first order (prune 2)
+// has no small bound -- it runs with the same rows as its cap (a ray beyond it goes to the redo list) + three rows of
+// slack, because one step pushes up to three entries before the cap is tested
+int stack_rows4(const EzrtScene* s) { return s->stack_need4 + (prune_mode(s) == 2 ? 3 : 0); }
 int records_staged4(const EzrtScene* s, int wps) {
-  const size_t lds_fixed = (size_t)s->stack_need4 * BLOCK * sizeof(int) + BLOCK * sizeof(int);
+  const size_t lds_fixed = (size_t)stack_rows4(s) * BLOCK * sizeof(int) + BLOCK * sizeof(int);
   size_t budget = (size_t)(158 * 1024) / (size_t)(wps > 0 ? wps : 1);
   if (budget > 64 * 1024) budget = 64 * 1024;
   budget -= budget / 16;
@@ -441,7 +464,7 @@ TraceCfg trace_cfg4(const EzrtScene* s, bool rel) {
   TraceCfg c;
   Tuning tu = s->tune;
   tu.trace_wps = wps4(s, rel);
-  c.lds = (size_t)s->stack_need4 * BLOCK * sizeof(int);
+  c.lds = (size_t)stack_rows4(s) * BLOCK * sizeof(int);
   const size_t lds_fixed = c.lds + BLOCK * sizeof(int);
   int blocks_per_cu = tu.trace_wps > 0 ? tu.trace_wps : 5;
   if ((size_t)blocks_per_cu * lds_fixed > 158 * 1024) blocks_per_cu = (int)((158 * 1024) / lds_fixed);
@@ -449,12 +472,13 @@ TraceCfg trace_cfg4(const EzrtScene* s, bool rel) {
   size_t lds_budget = (size_t)(158 * 1024) / blocks_per_cu;
   if (lds_budget > 64 * 1024) lds_budget = 64 * 1024;
   lds_budget -= lds_budget / 16;
-  int n = lds_budget > lds_fixed ? (int)((lds_budget - lds_fixed) / (N4_LDS_DWORDS * 4)) : 0;
+  const size_t rec_bytes = (size_t)N4_LDS_DWORDS * 4;
+  int n = lds_budget > lds_fixed ? (int)((lds_budget - lds_fixed) / rec_bytes) : 0;
   if (n > s->n_inner4) n = s->n_inner4;
   if (n > tu.lds_nodes) n = tu.lds_nodes;
   if (n < 0) n = 0;
   c.lds_nodes = n;
-  c.lds_t = lds_fixed + (size_t)n * (N4_LDS_DWORDS * 4);
+  c.lds_t = lds_fixed + (size_t)n * rec_bytes;
   c.blocks_per_cu = blocks_per_cu;
   c.grid_full = (unsigned)(s->num_cus * blocks_per_cu);
   return c;
@@ -462,12 +486,24 @@ TraceCfg trace_cfg4(const EzrtScene* s, bool rel) {
 // whether the timed stages of this scene run traceq4_kernel
 bool use_wide4(const EzrtScene* s) {
   return s->tune.wide4 && s->n_inner4 > 0 && s->instr == 0 &&
-         ((size_t)s->stack_need4 + 1) * BLOCK * sizeof(int) <= 60 * 1024; // stack rows + lane table
+         ((size_t)s->stack_need4 + 4) * BLOCK * sizeof(int) <= 60 * 1024; // stack rows (+ 3 of slack: prune 2) + lane table
 }
 template <bool REL, bool LOG>
 void launch_traceq4_v(EzrtScene* s, const TraceCfg& c, const TraceQ4Args& q, hipStream_t st) {
   const int trace_wps = wps4(s, REL);
   const dim3 grid(c.grid_full), block(BLOCK);
+  const int prune = prune_mode(s);
+  if (prune) { // (the pruning variants exist for the two register budgets the launches use: 7 and 6 waves per SIMD)
+    if (trace_wps >= 7) {
+      if (prune == 2) hipLaunchKernelGGL((traceq4_kernel<7, REL, LOG, 2>), grid, block, c.lds_t, st, q);
+      else hipLaunchKernelGGL((traceq4_kernel<7, REL, LOG, 1>), grid, block, c.lds_t, st, q);
+    } else {
+      if (prune == 2) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 2>), grid, block, c.lds_t, st, q);
+      else hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 1>), grid, block, c.lds_t, st, q);
+    }
+    s->n_trace_launches++;
+    return;
+  }
   if (trace_wps == 8) hipLaunchKernelGGL((traceq4_kernel<8, REL, LOG>), grid, block, c.lds_t, st, q);
   else if (trace_wps == 7) hipLaunchKernelGGL((traceq4_kernel<7, REL, LOG>), grid, block, c.lds_t, st, q);
   else if (trace_wps == 6) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG>), grid, block, c.lds_t, st, q);
@@ -492,6 +528,13 @@ void launch_traceq4_cfg(EzrtScene* s, const TraceCfg& c4, const TraceQArgs& t, c
   A.inner4_rel = rel;
   A.root4 = s->root4;
   A.lds_nodes4 = c4.lds_nodes;
+  {
+    // delta(ray) = (cz + cg max(M, |S|)) max |1/d|: twice the bound of ezrt_traceq4.h, constants rounded up
+    const double eps = 1.0 / 16777216.0;
+    A.prune_cs = __builtin_nextafterf((float)(2.0 * 17.0 * eps), __builtin_inff());
+    A.prune_a = s->prune_a;
+    A.stack_cap = s->stack_need4;
+  }
   if (rel) launch_traceq4_rel<true>(s, c4, A, st);
   else launch_traceq4_rel<false>(s, c4, A, st);
 }
@@ -1077,6 +1120,7 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
   // ---- 4-wide collapse for traceq4_kernel (ezrt_traceq4.h).  Valid only when every box is nested in its
   // parent's box (true for the reference builders; checked here because the arrays are the caller's).
   std::vector<float4> inner4;
+  std::vector<std::array<int, 4>> rec_slot_nodes; // per record (in its final numbering): the caller's node of each slot, 0 = unused
   int n_inner4 = 0, stack_need4 = 1;
   {
     std::vector<HostNode> hn((size_t)n_nodes);
@@ -1183,6 +1227,7 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
       }
       n_inner4 = (int)recs.size();
       inner4.assign((size_t)n_inner4 * N4_FLOAT4, make_float4(0, 0, 0, 0));
+      rec_slot_nodes.assign((size_t)n_inner4, std::array<int, 4>{0, 0, 0, 0});
       const float qnan = __builtin_nanf("");
       for (size_t q = 0; q < recs.size(); q++) {
         const Rec& r = recs[q];
@@ -1202,6 +1247,7 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
           memcpy(&v[6][k], &rf, 4);
         }
         if (number[q] < 0) return fail(EZRT_ERR_INVALID, "internal: 4-wide record %zu of node %d was never numbered", q, r.node);
+        for (int k = 0; k < r.m; k++) rec_slot_nodes[(size_t)number[q]][k] = r.slot[k];
         float4* o = &inner4[(size_t)number[q] * N4_FLOAT4];
         for (int c = 0; c < 3; c++) { // rows: see EZRT_SLAB_SELECT in ezrt_traceq4.h
           o[N4_ROW_AA + c] = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
@@ -1222,6 +1268,141 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
     geom[(size_t)i * 3 + 0] = make_float4(t[0], t[1], t[2], cx * inv);
     geom[(size_t)i * 3 + 1] = make_float4(t[3], t[4], t[5], cy * inv);
     geom[(size_t)i * 3 + 2] = make_float4(t[6], t[7], t[8], cz * inv);
+  }
+
+  // ---- distance pruning (ezrt_traceq4.h "Distance pruning"): the per-triangle bound eta_T in double precision, A = 2 max
+  // eta_T over the triangles below each slot (row 7 of the 4-wide records).  Leaf boxes must hold their triangles (true for
+  // the reference builders; these are the caller's arrays).
+  bool prunable = n_inner4 > 0;
+  double prune_G = 0.0, prune_Z = 0.0, prune_M = 0.0, prune_A_med = 0.0;
+  float prune_a = 0.0f;
+  uint32_t root4_flag = 0u;
+  int64_t prune_bad = 0, prune_flagged = 0;
+  if (prunable) {
+    for (int i = 1; i < n_nodes && prunable; i++) {
+      const HostNode h = decode_node(nodes, i);
+      if (h.n <= 0) continue;
+      for (int k = h.index; k < h.index + h.n && prunable; k++) {
+        const float* t = tri + (size_t)k * EZRT_TRI_FLOATS;
+        for (int v = 0; v < 9; v++)
+          if (!(t[v] >= h.AA[v % 3] && t[v] <= h.BB[v % 3])) prunable = false; // (false on NaN)
+      }
+    }
+  }
+  if (prunable) {
+    const double eps = 1.0 / 16777216.0, dinf = (double)__builtin_inff();
+    std::vector<double> eta((size_t)n_tri, 0.0);
+    for (int i = 0; i < n_tri; i++) {
+      const float* t = tri + (size_t)i * EZRT_TRI_FLOATS;
+      double p[3][3], n[3] = {(double)geom[(size_t)i * 3].w, (double)geom[(size_t)i * 3 + 1].w, (double)geom[(size_t)i * 3 + 2].w}, m_t = 0.0;
+      for (int v = 0; v < 3; v++)
+        for (int c = 0; c < 3; c++) {
+          p[v][c] = (double)t[v * 3 + c];
+          m_t = __builtin_fmax(m_t, p[v][c] < 0 ? -p[v][c] : p[v][c]);
+        }
+      prune_M = __builtin_fmax(prune_M, m_t);
+      const double nn = __builtin_sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+      if (!(nn == nn) || nn > 1e300 || nn == 0.0) continue; // NaN / inf / zero normal: hit_triangle_t can never accept it (eta = 0)
+      eta[(size_t)i] = dinf;                                  // until proven otherwise
+      if (!(m_t < 1e30) || !(nn > 0.5 && nn < 2.0)) { // a stored normal that is not unit (underflow in the cross product): no bound
+        prune_bad++;
+        continue;
+      }
+      double u[3] = {n[0] / nn, n[1] / nn, n[2] / nn}, q[3][3], zeta = 0.0;
+      for (int v = 0; v < 3; v++) {
+        const double h = u[0] * (p[v][0] - p[0][0]) + u[1] * (p[v][1] - p[0][1]) + u[2] * (p[v][2] - p[0][2]);
+        for (int c = 0; c < 3; c++) q[v][c] = p[v][c] - u[c] * h;
+        zeta = __builtin_fmax(zeta, h < 0 ? -h : h);
+      }
+      double smin = 1.0, diam = 0.0, emin = dinf; // min sin(angle / 2), longest and shortest edge of the projected triangle
+      for (int v = 0; v < 3; v++) {
+        const double* o = q[v];
+        const double* e = q[(v + 1) % 3];
+        const double* f = q[(v + 2) % 3];
+        const double a[3] = {e[0] - o[0], e[1] - o[1], e[2] - o[2]}, b[3] = {f[0] - o[0], f[1] - o[1], f[2] - o[2]};
+        const double la = __builtin_sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), lb = __builtin_sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+        diam = __builtin_fmax(diam, la);
+        emin = __builtin_fmin(emin, la);
+        if (!(la > 0.0 && lb > 0.0)) {
+          smin = 0.0;
+          break;
+        }
+        double c = (a[0] * b[0] + a[1] * b[1] + a[2] * b[2]) / (la * lb);
+        c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+        smin = __builtin_fmin(smin, __builtin_sqrt((1.0 - c) * 0.5));
+      }
+      if (!(smin >= 1e-4) || !(zeta <= 1e-3 * emin)) { // thinner than ~0.01 degrees, or bent off its stored plane: no bound
+        prune_bad++;
+        continue;
+      }
+      eta[(size_t)i] = zeta + 15.2 * eps * (diam + zeta) / smin + 19.8 * eps * m_t;
+      prune_G = __builtin_fmax(prune_G, 1.0 / smin);
+      prune_Z = __builtin_fmax(prune_Z, zeta);
+    }
+    // ordinary triangles: eta_T <= cutoff.  cutoff = 2^-13 max|coordinate| when that already leaves a margin that is small
+    // at the scale the geometry lives on (<= 2^-14 of the median triangle's largest coordinate); otherwise -- a ground
+    // plane of kilometres under a metre-sized model -- the 1 - 2^-10 quantile of the bounds.  The others flag every node above them.
+    double cutoff = prune_M / 8192.0;
+    {
+      std::vector<double> all, mts;
+      double a_glob = 0.0;
+      for (int i = 0; i < n_tri; i++) {
+        const float* t = tri + (size_t)i * EZRT_TRI_FLOATS;
+        double m_t = 0.0;
+        for (int v = 0; v < 9; v++) m_t = __builtin_fmax(m_t, (double)(t[v] < 0 ? -t[v] : t[v]));
+        mts.push_back(m_t);
+        if (eta[(size_t)i] > 0.0 && eta[(size_t)i] < dinf) all.push_back(eta[(size_t)i]);
+        if (eta[(size_t)i] <= cutoff) a_glob = __builtin_fmax(a_glob, eta[(size_t)i]);
+      }
+      std::nth_element(mts.begin(), mts.begin() + mts.size() / 2, mts.end());
+      const double scale = mts[mts.size() / 2];
+      if (a_glob > scale / 16384.0 && all.size() >= 2048) {
+        const size_t k = all.size() - 1 - all.size() / 1024;
+        std::nth_element(all.begin(), all.begin() + k, all.end());
+        cutoff = __builtin_fmin(cutoff, all[k]);
+      }
+    }
+    double a_max = 0.0;
+    std::vector<double> fin;
+    for (int i = 0; i < n_tri; i++) {
+      if (eta[(size_t)i] <= cutoff) {
+        a_max = __builtin_fmax(a_max, eta[(size_t)i]);
+        if (eta[(size_t)i] > 0.0) fin.push_back(eta[(size_t)i]);
+      } else if (eta[(size_t)i] < dinf) {
+        prune_bad++; // (a bound, but a useless one)
+      }
+    }
+    if (!fin.empty()) {
+      std::nth_element(fin.begin(), fin.begin() + fin.size() / 2, fin.end());
+      prune_A_med = 2.0 * fin[fin.size() / 2];
+    }
+    prune_a = __builtin_nextafterf((float)(2.0 * a_max), __builtin_inff());
+    std::vector<unsigned char> node_flag((size_t)n_nodes, 0); // (ids are topologically ordered: children after parents)
+    for (int i = n_nodes - 1; i >= 1; i--) {
+      const HostNode h = decode_node(nodes, i);
+      unsigned char f = 0;
+      if (h.n > 0) {
+        for (int k = h.index; k < h.index + h.n; k++) f |= eta[(size_t)k] > cutoff;
+      } else {
+        f = node_flag[(size_t)h.left] | node_flag[(size_t)h.right];
+      }
+      node_flag[(size_t)i] = f;
+    }
+    // REF_NOPRUNE on every reference to a record with such a triangle below it (and on the root reference)
+    for (size_t q = 0; q < rec_slot_nodes.size(); q++) {
+      uint32_t rf[4];
+      memcpy(rf, &inner4[q * N4_FLOAT4 + N4_ROW_REF], sizeof rf);
+      for (int k = 0; k < 4; k++) {
+        const int nd = rec_slot_nodes[q][k];
+        if (nd > 0 && (int32_t)rf[k] >= 0 && node_flag[(size_t)nd]) {
+          rf[k] |= REF_NOPRUNE;
+          prune_flagged++;
+        }
+      }
+      memcpy(&inner4[q * N4_FLOAT4 + N4_ROW_REF], rf, sizeof rf);
+    }
+    root4_flag = node_flag[1] ? REF_NOPRUNE : 0u;
+    if (root4_flag) prune_flagged++;
   }
 
   // ---- shading records + table of distinct materials (bitwise distinct 18-float tuples)
@@ -1298,7 +1479,15 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
   SC_TRY(hipMemcpy(s->inner.p, inner.data(), inner.size() * sizeof(float4), hipMemcpyHostToDevice));
   s->n_inner4 = n_inner4;
   s->stack_need4 = stack_need4;
-  s->root4 = n_inner4 > 0 ? 0u : s->root_ref;
+  s->prunable = prunable;
+  s->prune_G = prune_G;
+  s->prune_Z = prune_Z;
+  s->prune_M = prune_M;
+  s->prune_A_med = prune_A_med;
+  s->prune_a = prune_a;
+  s->prune_bad = prune_bad;
+  s->prune_flagged = prune_flagged;
+  s->root4 = n_inner4 > 0 ? root4_flag : s->root_ref;
   if (n_inner4 > 0) {
     SC_TRY(s->inner4.ensure(inner4.size()));
     SC_TRY(hipMemcpy(s->inner4.p, inner4.data(), inner4.size() * sizeof(float4), hipMemcpyHostToDevice));
@@ -1817,6 +2006,16 @@ int ezrt_last_render_ms(EzrtScene* s, float* total_ms, float* trace_kernel_ms, i
   if (total_ms) *total_ms = tot;
   if (trace_kernel_ms) *trace_kernel_ms = tr;
   if (n_trace_launches) *n_trace_launches = s->n_trace_launches;
+  return 0;
+}
+int ezrt_scene_prune_info(EzrtScene* s, double out[6]) {
+  if (!s || !out) return fail(EZRT_ERR_INVALID, "NULL argument");
+  out[0] = s->prunable ? (double)prune_mode(s) : -1.0;
+  out[1] = s->prune_G;
+  out[2] = s->prune_Z;
+  out[3] = s->prune_M;
+  out[4] = (double)s->prune_bad;
+  out[5] = (double)s->prune_a;
   return 0;
 }
 int ezrt_scene_stats(EzrtScene* s, int64_t out[6]) {

@@ -54,6 +54,8 @@ constexpr int N4_ROW_AA = 0, N4_ROW_BB = 3, N4_ROW_REF = 6;
 constexpr uint32_t REF_EMPTY = 0xfffffffdu; // unused slot of a 4-wide record
 constexpr int N4_FLOAT4 = 8;                // record stride in HBM, float4s (7 used)
 constexpr int N4_LDS_DWORDS = 28;           // record stride in LDS: 112 B; 28 r mod 64 hits 16 distinct bank quads
+constexpr uint32_t REF_NOPRUNE = 0x40000000u; // inner reference (and root4): a triangle without a useful bound lies below this record
+constexpr uint32_t REF_INDEX = 0x00ffffffu;   // ... its record index
 
 struct TraceQ4Args {
   TraceQArgs q;             // queue, pools, counters, redo list, knobs (q.lds_nodes is unused here)
@@ -61,7 +63,46 @@ struct TraceQ4Args {
   const float4* inner4_rel; // q.const_origin only (or NULL): the same with every box translated by -origin
   uint32_t root4;           // reference of the root: record 0, or the root leaf
   int32_t lds_nodes4;       // records [0, lds_nodes4) staged in LDS
+  // PRUNE > 0 (see "Distance pruning" below): delta(ray) = (prune_a + prune_cs * |S|_inf) * max_k |1/d_k|
+  float prune_a, prune_cs;
+  int32_t stack_cap;        // PRUNE == 2: live stack rows beyond which a ray is handed to the redo list (the launch
+                            // allocates stack_cap + 3 rows: one step pushes at most three)
 };
+
+// ---- Distance pruning (PRUNE > 0): results-neutral, proven, not merely observed.
+//
+// The reference's hitBVH never prunes (P5/fsh:254-306), so the result of a ray is the minimum of t over every triangle
+// whose leaf the box tests let it reach.  A slot may be SKIPPED without changing that minimum -- or the set of
+// triangles that tie with it -- if no triangle below it can be accepted with t <= best_t.  Claim: if hit_triangle_t
+// accepts triangle T (vertices inside the slot's box B: ezrt_scene_create verifies every leaf and every nesting) with
+// distance t, then for every axis k, with eps = 2^-24, s = |S|_inf, m_T = the largest |coordinate| of T's vertices,
+//        t  >=  t0_k(B) - (eta_T + 17 eps s) |inv_k| (1 + eps) - 3.1 eps |t0_k| - eps t,
+//        eta_T = a_T + 19.8 eps m_T,      a_T = zeta_T + 15.2 eps (diam_T + zeta_T) / sin(theta'_T / 2),
+// where t0_k = fl(fl(near_k - S_k) inv_k) is the slab test's entry product, zeta_T = max_i |N.(p_i - p1)| / |N| the
+// distance of T's vertices from the plane through p1 with the STORED normal N, theta'_T the smallest angle and diam_T the
+// longest edge of T projected along N.  Proof (long form: DESIGN.md 5).  An accepted hit passed the three edge tests on
+// the fp32 point P = fl(S + fl(d t)).  (i) P lies within eps (17.5 m_T + 15.8 s) of that plane however small |N.d| is:
+// N.(P* - p1) = e_num + eps2 num - t e_den for P* = S + d t -- the rounding errors of the two dot products, the
+// subtraction and the division, NOT divided by N.d: an error of t moves P along the ray, and the plane distance is
+// measured across it.  (ii) The edge tests only see projections along N; each computed sign is exact up to
+// 15.01 eps |edge| |P - p_i| and |P - p_i| is itself of the size of T (fl(P - p_i) has a RELATIVE error), so the
+// projection P' lies within 15.05 eps |P - p_i| of each half-plane of the projected triangle T', hence within
+// 15.2 eps (diam_T + zeta_T) / sin(theta'/2) of T' -- the wedge at a corner lets a point that far past the tip; this is
+// the term a sliver inflates, and why it is kept PER TRIANGLE.  (iii) T' is within zeta_T of T, and T is inside B.  So
+// P_k >= AA_k - eta_T - 15.8 eps s (and <= BB_k + ...); finally P_k = fl(S_k + fl(d_k t)) ties t to (P_k - S_k) / d_k
+// up to eps (2.02 m_T + 2 a_T + s) |inv_k|.
+// eta_T is evaluated per triangle in double precision at scene creation.  Triangles are split into ORDINARY ones,
+// eta_T <= 2^-13 max|coordinate| -- or, where that is not small at the scale of the median triangle, the 1 - 2^-10 quantile
+// of the bounds -- (everything but slivers and triangles far from the origin: the thin side faces of a flattened box, a
+// ground plane of kilometres), whose maximum gives the launch's prune_a = 2 max eta_T (safety factor 2, rounded up; prune_cs = 2 * 17 eps),
+// and the rest -- larger eta_T, or no bound at all (sin(theta'/2) < 1e-4, zeta_T > 1e-3 of the shortest edge, |N| not 1):
+// every record above such a triangle carries REF_NOPRUNE in the references to it and none of its slots is ever skipped.
+// A leaf box that does not hold its triangles switches pruning off for the whole scene.  A slot is skipped iff
+//        t0 = max_k t0_k  >  (best_t + (prune_a + prune_cs s) max_k |inv_k|) (1 + 2^-19)          (strict).
+// Then every triangle below it has t > best_t: it can neither win nor tie, so the hit record AND the tie detection (redo
+// list) are those of the unpruned traversal.  Counters P/I/T/M stay the unpruned reference's: they come from
+// traceq_kernel, which does not prune.
+constexpr float PRUNE_REL = 1.0f + 1.0f / 524288.0f; // 1 + 2^-19 = 1 + 32 eps: covers 3.1 eps |t0| + eps t and the two roundings here
 
 // 4-wide records with every box translated by -S: (AA - S, BB - S), the subtraction hitAABB does per visit
 EZD void inner4_translate(const float4* in, int i, float sx, float sy, float sz, float4* out) {
@@ -105,7 +146,7 @@ EZD void chunk_prologue(const ChunkPrologue& g, uint32_t tid, uint32_t n_threads
 // LOG: the per-wave diagnostics of debug_stages=2 (a.wave_log).  A template parameter, not a run-time test: the
 // counters and time stamps are loop-carried values, and even never-executed they cost the production kernel registers
 // (one 64-bit time stamp turned 4 spills into 7: -2 %).
-template <int WPS, bool REL, bool LOG = false>
+template <int WPS, bool REL, bool LOG = false, int PRUNE = 0>
 __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
   extern __shared__ __attribute__((aligned(16))) int lds_stack[];
   const TraceQArgs& a = A.q;
@@ -146,7 +187,14 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
   uint32_t ref = REF_NONE;
   uint32_t n_counted = 0;
   unsigned long long* hits64 = reinterpret_cast<unsigned long long*>(a.hits);
-
+  // PRUNE: a slot is skipped when its entry distance exceeds prune_t = (best_t + pdelta)(1 + 2^-19),
+  //   pdelta = (prune_a + prune_cs |S|_inf) max_k |inv_k|
+  float prune_t = INF, pdelta = 0.0f;
+  auto set_delta = [&]() {
+    const float sm = REL ? hw_max3(ez_abs(a.origin[0]), ez_abs(a.origin[1]), ez_abs(a.origin[2])) : hw_max3(ez_abs(S.x), ez_abs(S.y), ez_abs(S.z));
+    pdelta = (A.prune_a + A.prune_cs * sm) * hw_max3(ez_abs(inv.x), ez_abs(inv.y), ez_abs(inv.z));
+    prune_t = (best_t + pdelta) * PRUNE_REL;
+  };
   auto to_redo = [&](uint32_t s) { // (rare) the in-order binary kernel decides this ray
     if (atomicExch(&a.redo_flag[s], 1u) == 0u) a.redo_slots[atomicAdd(a.redo_count, 1u)] = s;
     // until it has, the record says so: key (t bits 0, tri HIT_PENDING) is below every real key, so later atomicMin
@@ -179,6 +227,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
     if (t < best_t) {
       best_t = t;
       best_tri = tri;
+      if (PRUNE) prune_t = (t + pdelta) * PRUNE_REL;
     } else if (t == best_t && tri != best_tri) {
       tie = true;
     }
@@ -216,6 +265,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
           tie = !ray_is_tame(S, inv) || (a.force_pending && adopted % a.force_pending == 0u);
           ref = tie ? REF_DONE : A.root4;
           best_tri = tie ? HIT_PENDING : -1;
+          if (PRUNE) set_delta();
         }
       }
       const bool need = nx_slot == REF_NONE && !exhausted;
@@ -303,6 +353,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
             sp = 0;
             sb = 0;
             ref = (uint32_t)got;
+            if (PRUNE) set_delta();
           }
         }
       }
@@ -325,8 +376,11 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
       const uint32_t kx = (__float_as_uint(inv.x) >> 31) << 6, ky = (__float_as_uint(inv.y) >> 31) << 6,
                      kz = (__float_as_uint(inv.z) >> 31) << 6;
       v4f nx, ny, nz, fx, fy, fz, rfv;
-      if (ref < (uint32_t)A.lds_nodes4) { // top of the tree: staged in LDS
-        lds_char* lb = (lds_char*)lds_nodes + ref * (uint32_t)(N4_LDS_DWORDS * 4);
+      // PRUNE: a reference may carry REF_NOPRUNE (nothing below this record is ever skipped)
+      const uint32_t rec = ref & REF_INDEX; // (also when PRUNE == 0: the flag is part of the scene's records, the mode is a knob)
+      const float thr = (PRUNE && ref >= REF_NOPRUNE) ? __builtin_inff() : prune_t;
+      if (rec < (uint32_t)A.lds_nodes4) { // top of the tree: staged in LDS
+        lds_char* lb = (lds_char*)lds_nodes + rec * (uint32_t)(N4_LDS_DWORDS * 4);
         nx = *(lds_v4f*)(lb + kx);
         ny = *(lds_v4f*)(lb + 16u + ky);
         nz = *(lds_v4f*)(lb + 32u + kz);
@@ -338,7 +392,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
         // (32-bit offsets from the uniform table pointer: global_load with an SGPR base and one VGPR offset each,
         // no 64-bit address arithmetic; the table is < 2^32 bytes: n_inner4 < 2^24 records of 128 B)
         const char* tab = reinterpret_cast<const char*>(inner);
-        const uint32_t roff = ref * (uint32_t)(N4_FLOAT4 * 16);
+        const uint32_t roff = rec * (uint32_t)(N4_FLOAT4 * 16);
         nx = *reinterpret_cast<const v4f*>(tab + (uint32_t)(roff + kx));
         ny = *reinterpret_cast<const v4f*>(tab + (uint32_t)(roff + ky + 16u));
         nz = *reinterpret_cast<const v4f*>(tab + (uint32_t)(roff + kz + 32u));
@@ -348,7 +402,8 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
         rfv = *reinterpret_cast<const v4f*>(tab + (uint32_t)(roff + 48u));
       }
       const float4 rf = make_float4(rfv.x, rfv.y, rfv.z, rfv.w);
-      auto slab = [&](float nxk, float nyk, float nzk, float fxk, float fyk, float fzk) -> bool {
+      float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f, e3 = 0.0f; // PRUNE == 2: entry distances of the four slots
+      auto slab = [&](float nxk, float nyk, float nzk, float fxk, float fyk, float fzk, float& entry) -> bool {
         float t0x, t0y, t0z, t1x, t1y, t1z;
         if (REL) { // boxes already translated by the common origin
           t0x = nxk * inv.x, t0y = nyk * inv.y, t0z = nzk * inv.z;
@@ -359,13 +414,18 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
         }
         const float t1 = hw_min3(t1x, t1y, t1z);
         const float t0 = hw_max3(t0x, t0y, t0z);
-        return (t1 >= t0) && (t1 > 0.0f); // == hitAABB(..) > 0
+        if (PRUNE == 2) entry = t0;
+        // == hitAABB(..) > 0; PRUNE: ... and not provably beyond the best hit so far (see "Distance pruning")
+        if (PRUNE) return (t1 >= t0) && (t1 > 0.0f) && !(t0 > thr);
+        return (t1 >= t0) && (t1 > 0.0f);
       };
-      const bool h0 = slab(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x);
-      const bool h1 = slab(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y);
-      const bool h2 = slab(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z);
-      const bool h3 = slab(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w);
+      const bool h0 = slab(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, e0);
+      const bool h1 = slab(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, e1);
+      const bool h2 = slab(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, e2);
+      const bool h3 = slab(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, e3);
 #else
+      static_assert(PRUNE == 0, "distance pruning is implemented on the EZRT_SLAB_SELECT form of the slab test");
+      const float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f, e3 = 0.0f;
       float4 ax, ay, az, bx, by, bz, rf;
       if (ref < (uint32_t)A.lds_nodes4) { // top of the tree: staged in LDS
         lds_v4f* r = (lds_v4f*)(lds_nodes + ref * 7u);
@@ -407,6 +467,48 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
 #endif
       const uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z),
                      r3 = __float_as_uint(rf.w);
+      if (PRUNE == 2) {
+        // nearest first: continue with the hit slot of the smallest entry distance (so that the first leaves a ray
+        // reaches are the likely winners and the rest gets pruned), push the other hit slots highest-first.  The order
+        // is a heuristic only: pruning is exact whatever the order, exact ties still go to the redo list.
+        const float inf = __builtin_inff();
+        const float k0 = h0 ? e0 : inf, k1 = h1 ? e1 : inf, k2 = h2 ? e2 : inf, k3 = h3 ? e3 : inf;
+        const float km = hw_min(hw_min3(k0, k1, k2), k3);
+        const bool s0 = h0 && k0 == km;
+        const bool s1 = !s0 && h1 && k1 == km;
+        const bool s2 = !s0 && !s1 && h2 && k2 == km;
+        const bool s3 = !s0 && !s1 && !s2 && h3;
+        if (h3 && !s3) {
+          stack[sp * BLOCK] = (int)r3;
+          sp++;
+        }
+        if (h2 && !s2) {
+          stack[sp * BLOCK] = (int)r2;
+          sp++;
+        }
+        if (h1 && !s1) {
+          stack[sp * BLOCK] = (int)r1;
+          sp++;
+        }
+        if (h0 && !s0) {
+          stack[sp * BLOCK] = (int)r0;
+          sp++;
+        }
+        if (h0 || h1 || h2 || h3) {
+          ref = s0 ? r0 : (s1 ? r1 : (s2 ? r2 : r3));
+          // this order has no small worst-case stack bound (up to three pending entries per level): a ray that would
+          // need more rows than the launch has is handed to the redo list (in-order binary kernel, any depth <= 63)
+          if (sp - sb > A.stack_cap) {
+            tie = true;
+            finish();
+          }
+        } else if (sp > sb) {
+          sp--;
+          ref = (uint32_t)stack[sp * BLOCK];
+        } else {
+          finish();
+        }
+      } else {
       // visit the hit slots in ascending order: continue with the lowest, push the others highest-first
       if (h3 && (h0 || h1 || h2)) {
         stack[sp * BLOCK] = (int)r3;
@@ -427,6 +529,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
         ref = (uint32_t)stack[sp * BLOCK];
       } else {
         finish();
+      }
       }
     }
 

@@ -126,6 +126,11 @@ class Scene:
         self._ck(self._tl.lib.ezrt_last_render_ms(self._h, C.byref(a), C.byref(b), C.byref(n)))
         return a.value, b.value, n.value
 
+    def prune_info(self):
+        out = (C.c_double * 6)()
+        self._ck(self._tl.lib.ezrt_scene_prune_info(self._h, out))
+        return dict(zip(("mode", "G", "Z", "M", "unprunable_triangles", "margin_a"), [float(x) for x in out]))
+
     def stats(self):
         out = (C.c_int64 * 6)()
         self._ck(self._tl.lib.ezrt_scene_stats(self._h, out))

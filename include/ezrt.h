@@ -176,6 +176,14 @@ int ezrt_last_render_ms(EzrtScene* s, float* total_ms, float* trace_kernel_ms, i
  * [3] nLeaves [4] max leaf size [5] device bytes. */
 int ezrt_scene_stats(EzrtScene* s, int64_t out[6]);
 
+/* What the scene allows the trace's distance pruning to do (a schedule matter: results never depend on it; the proof
+ * and its per-triangle bound are in ezrt_amd/csrc/hip/ezrt_traceq4.h): [0] pruning mode in use (0 off, 1 prune, 2 prune +
+ * nearest slot first; -1: not available for this scene -- a leaf box that does not hold its triangles, or boxes that are
+ * not nested) [1] max 1/sin(theta'/2) over the triangles with a bound [2] max distance of a vertex from its triangle's
+ * stored plane [3] max |coordinate| [4] triangles with a large bound or none (slivers: the records above them are never
+ * pruned) [5] the launch's margin coefficient a.  The oracle (which never prunes) reports -1 and zeros. */
+int ezrt_scene_prune_info(EzrtScene* s, double out[6]);
+
 /* Evaluate the deterministic math definitions on the implementation's compute
  * device (GPU for libezrt_hip) for the bit-equality test.  op: 0 sin, 1 cos,
  * 2 atan2(a,b), 3 asin, 4 log, 5 exp, 6 pow(a,b), 7 sqrt, 8 a/b, 9 wang-hash
