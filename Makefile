@@ -54,4 +54,10 @@ clean:
 	rm -f $(LIBDIR)/*.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all host hip oracle examples clean
+.PHONY: all host hip oracle examples clean negctl
+
+# negative control of tests/test_gpu_prune.py (tools/gpu_negctl.sh): the HIP library with a pruning margin that is
+# negative on purpose; never loaded by the product (EZRT_HIP_LIB selects it for that one run)
+negctl:
+	@mkdir -p build_ab
+	$(HIPCC) $(HIP_FLAGS) -DEZRT_PRUNE_NEGATIVE_CONTROL=1 -shared -o build_ab/libezrt_hip_negctl.so $(HIP_SRC) -ldl

@@ -113,6 +113,7 @@ struct Tuning {
   int prune = 2;           // traceq4_kernel's distance pruning (ezrt_traceq4.h "Distance pruning": proven results-neutral): 0 the
                            // reference's unpruned traversal, 1 skip slots provably beyond the best hit, 2 that + nearest slot first
   int prune_min_records = 0; // scenes with fewer 4-wide records than this are traced unpruned (small trees gain nothing)
+  int debug_stack_cap = 0; // test hook (prune 2): > 0 = stack rows beyond which a ray goes to the redo list, instead of the scene's bound
   int audit_via_queue = 0; // 1: ezrt_query_hits and ezrt_render_paths run through the TIMED kernels (traceq_kernel with
                            // the template, LDS layout, stealing and redo launch of a render call + the streaming shading
                            // stages) instead of the in-order audit kernels; 2 (query only): additionally treat the rays as
@@ -153,6 +154,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"debug_oom_above", &Tuning::debug_oom_above, 0, 1 << 30},
                               {"prune", &Tuning::prune, 0, 2},
                               {"prune_min_records", &Tuning::prune_min_records, 0, 1 << 24},
+                              {"debug_stack_cap", &Tuning::debug_stack_cap, 0, 64},
                               {"audit_via_queue", &Tuning::audit_via_queue, 0, 2}};
 Tuning tuning_from_env() {
   Tuning t;
@@ -533,7 +535,7 @@ void launch_traceq4_cfg(EzrtScene* s, const TraceCfg& c4, const TraceQArgs& t, c
     const double eps = 1.0 / 16777216.0;
     A.prune_cs = __builtin_nextafterf((float)(2.0 * 17.0 * eps), __builtin_inff());
     A.prune_a = s->prune_a;
-    A.stack_cap = s->stack_need4;
+    A.stack_cap = (s->tune.debug_stack_cap > 0 && s->tune.debug_stack_cap < s->stack_need4) ? s->tune.debug_stack_cap : s->stack_need4;
   }
   if (rel) launch_traceq4_rel<true>(s, c4, A, st);
   else launch_traceq4_rel<false>(s, c4, A, st);

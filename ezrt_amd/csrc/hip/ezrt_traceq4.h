@@ -102,7 +102,14 @@ struct TraceQ4Args {
 // Then every triangle below it has t > best_t: it can neither win nor tie, so the hit record AND the tie detection (redo
 // list) are those of the unpruned traversal.  Counters P/I/T/M stay the unpruned reference's: they come from
 // traceq_kernel, which does not prune.
-constexpr float PRUNE_REL = 1.0f + 1.0f / 524288.0f; // 1 + 2^-19 = 1 + 32 eps: covers 3.1 eps |t0| + eps t and the two roundings here
+// EZRT_PRUNE_NEGATIVE_CONTROL (never defined in the product build): a library variant whose margin is NEGATIVE -- it skips
+// slots up to 1e-3 of the distance IN FRONT of the best hit -- so that tools/gpu_negctl.sh can show that
+// tests/test_gpu_prune.py does catch a traversal that prunes too much.
+#ifdef EZRT_PRUNE_NEGATIVE_CONTROL
+constexpr float PRUNE_REL = 1.0f - 1.0f / 1024.0f;
+#else
+constexpr float PRUNE_REL = 1.0f + 1.0f / 524288.0f;
+#endif // 1 + 2^-19 = 1 + 32 eps: covers 3.1 eps |t0| + eps t and the two roundings here
 
 // 4-wide records with every box translated by -S: (AA - S, BB - S), the subtraction hitAABB does per visit
 EZD void inner4_translate(const float4* in, int i, float sx, float sy, float sz, float4* out) {
@@ -498,7 +505,8 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
           ref = s0 ? r0 : (s1 ? r1 : (s2 ? r2 : r3));
           // this order has no small worst-case stack bound (up to three pending entries per level): a ray that would
           // need more rows than the launch has is handed to the redo list (in-order binary kernel, any depth <= 63)
-          if (sp - sb > A.stack_cap) {
+          // (sp, not sp - sb: rows are addressed absolutely, and a thief taking the bottom row does not move the top)
+          if (sp > A.stack_cap) {
             tie = true;
             finish();
           }

@@ -284,7 +284,10 @@ def test_schedule_knobs_never_change_results(hip, bunny_small):
                      {"wide4": 0, "rel_boxes": 0}, {"tail_stage": 2}, {"tail_stage": 3, "wide4": 0}, {"refill_min": 16},
                      {"redo_overlap": 0}, {"launch_events": 1}, {"chunk_log2": 12}, {"chunk_log2": 16}, {"shade_wgs": 1}, {"shade_wgs": 4096}, {"debug_oom_above": 30000}, {"debug_oom_above": 45000}, {"env_rgbe": 0}, {"env_planes": 0}, {"trace_wps_rel": 0}, {"trace_wps_rel": 5}, {"debug_force_pending": 3}, {"debug_force_pending": 1},
                      {"debug_force_pending": 5, "redo_overlap": 0}, {"debug_force_pending": 2, "split_shade": 2},
-                     {"debug_force_pending": 7, "split_shade": 1}, {"debug_force_pending": 4, "split_shade": 0}):
+                     {"debug_force_pending": 7, "split_shade": 1}, {"debug_force_pending": 4, "split_shade": 0},
+                     {"prune": 0}, {"prune": 1}, {"prune": 2}, {"prune": 1, "steal": 0}, {"prune": 2, "debug_stack_cap": 1},
+                     {"prune": 2, "debug_stack_cap": 3, "redo_overlap": 0}, {"prune": 2, "lds_nodes": 0}, {"prune": 1, "trace_wps": 4},
+                     {"prune": 2, "prune_min_records": 1 << 20}):
             s2 = bunny_small.upload(hip)
             for k, v in opts.items():
                 s2.set_option(k, v)
