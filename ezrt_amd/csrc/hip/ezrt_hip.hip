@@ -90,6 +90,13 @@ struct Tuning {
   int wide4 = 1;           // traceq4_kernel (4-wide collapse of the tree, ezrt_traceq4.h) for the timed stages; 0: the
                            // binary traceq_kernel.  Instrumented runs (level 1) and scenes whose boxes are not
                            // nested always use the binary kernel.
+  int path_stage = 0;      // from this stage on (>= 2; 0: never -- the default) the surviving paths of a chunk finish in ONE launch of
+                           // pathq4_kernel (integrators without MIS, 4-wide records): a lane keeps its path and is shaded in the
+                           // refill block.  MEASURED SLOWER on C2: stages 2-4 take 450 us staged, 800-1000 us fused (2.59-2.93 vs
+                           // 2.18 ms per step; path_refill_min 56 is the best setting): the longest PATH is about the sum of the stages'
+                           // deepest rays (the same paths stay deep), and every shading batch stalls its wave's live traversals
+                           // for the ~10 us of its dependent loads at 4 waves per SIMD.  Kept as a tested knob.
+  int path_refill_min = 0; // refill_min of that launch (0: the trace launches' value)
   int tail_stage = 0;      // from this stage on (>= 2; 0: never -- the default: measured 1.95 ms vs 0.43 ms for stages 2-4 of C2) the surviving paths finish in tail_kernel, one lane per
                            // path, instead of one trace + shading stage per bounce (ezrt_wavefront.h)
   int debug_stages = 0;    // print per-stage queue sizes (synchronises)
@@ -110,6 +117,9 @@ struct Tuning {
                            // record costs the stream ~5 us: -1.2 % on C2); 0: only the call's begin / end events
   int env_planes = 1;      // the env cache as an (x, y) plane and a pdf plane for bilinear lookups (one load per row)
   int env_rgbe = 1;        // environment lookups through the 4-byte RGBE form of the map when it has an exact one (set_env)
+  int rel_min_records = 24; // the primary stage runs at trace_wps_rel waves per SIMD only while that leaves this many top-of-tree records in LDS
+  int gen_primary = 1;     // primary rays are generated inside the primary stage's trace and shading kernels (primary_dir) instead of
+                           // written to a queue by raygen_kernel (timed pipeline with the 4-wide, eye-relative records only)
   int prune = 2;           // traceq4_kernel's distance pruning (ezrt_traceq4.h "Distance pruning": proven results-neutral): 0 the
                            // reference's unpruned traversal, 1 skip slots provably beyond the best hit, 2 that + nearest slot first
   int prune_min_records = 0; // scenes with fewer 4-wide records than this are traced unpruned (small trees gain nothing)
@@ -143,6 +153,8 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"scatter", &Tuning::scatter, 0, 8},
                               {"wide4", &Tuning::wide4, 0, 1},
                               {"tail_stage", &Tuning::tail_stage, 0, 64},
+                              {"path_stage", &Tuning::path_stage, 0, 64},
+                              {"path_refill_min", &Tuning::path_refill_min, 0, 64},
                               {"debug_stages", &Tuning::debug_stages, 0, 2},
                               {"env_rgbe", &Tuning::env_rgbe, 0, 1},
                               {"env_planes", &Tuning::env_planes, 0, 1},
@@ -152,6 +164,8 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"redo_overlap", &Tuning::redo_overlap, 0, 1},
                               {"debug_force_pending", &Tuning::debug_force_pending, 0, 1 << 20},
                               {"debug_oom_above", &Tuning::debug_oom_above, 0, 1 << 30},
+                              {"gen_primary", &Tuning::gen_primary, 0, 1},
+                              {"rel_min_records", &Tuning::rel_min_records, 0, 4096},
                               {"prune", &Tuning::prune, 0, 2},
                               {"prune_min_records", &Tuning::prune_min_records, 0, 1 << 24},
                               {"debug_stack_cap", &Tuning::debug_stack_cap, 0, 64},
@@ -458,7 +472,7 @@ int records_staged4(const EzrtScene* s, int wps) {
 }
 int wps4(const EzrtScene* s, bool rel) {
   const int w = s->tune.trace_wps_rel;
-  if (rel && w > 0 && (w <= s->tune.trace_wps || records_staged4(s, w) >= std::min(24, s->n_inner4))) return w;
+  if (rel && w > 0 && (w <= s->tune.trace_wps || records_staged4(s, w) >= std::min(s->tune.rel_min_records, s->n_inner4))) return w;
   return s->tune.trace_wps;
 }
 // rel: the launch traverses boxes translated by a common origin (traceq4_kernel<.., true>)
@@ -490,20 +504,22 @@ bool use_wide4(const EzrtScene* s) {
   return s->tune.wide4 && s->n_inner4 > 0 && s->instr == 0 &&
          ((size_t)s->stack_need4 + 4) * BLOCK * sizeof(int) <= 60 * 1024; // stack rows (+ 3 of slack: prune 2) + lane table
 }
-template <bool REL, bool LOG>
+template <bool REL, bool LOG, bool GEN>
 void launch_traceq4_v(EzrtScene* s, const TraceCfg& c, const TraceQ4Args& q, hipStream_t st) {
   const int trace_wps = wps4(s, REL);
   const dim3 grid(c.grid_full), block(BLOCK);
   const int prune = prune_mode(s);
-  if (prune) { // (the pruning variants exist for the two register budgets the launches use: 7 and 6 waves per SIMD)
+  s->n_trace_launches++;
+  if (prune || GEN) { // (these variants exist for the two register budgets the launches use: 7 and 6 waves per SIMD)
     if (trace_wps >= 7) {
-      if (prune == 2) hipLaunchKernelGGL((traceq4_kernel<7, REL, LOG, 2>), grid, block, c.lds_t, st, q);
-      else hipLaunchKernelGGL((traceq4_kernel<7, REL, LOG, 1>), grid, block, c.lds_t, st, q);
+      if (prune == 2) hipLaunchKernelGGL((traceq4_kernel<7, REL, LOG, 2, GEN>), grid, block, c.lds_t, st, q);
+      else if (prune == 1) hipLaunchKernelGGL((traceq4_kernel<7, REL, LOG, 1, GEN>), grid, block, c.lds_t, st, q);
+      else hipLaunchKernelGGL((traceq4_kernel<7, REL, LOG, 0, GEN>), grid, block, c.lds_t, st, q);
     } else {
-      if (prune == 2) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 2>), grid, block, c.lds_t, st, q);
-      else hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 1>), grid, block, c.lds_t, st, q);
+      if (prune == 2) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 2, GEN>), grid, block, c.lds_t, st, q);
+      else if (prune == 1) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 1, GEN>), grid, block, c.lds_t, st, q);
+      else hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 0, GEN>), grid, block, c.lds_t, st, q);
     }
-    s->n_trace_launches++;
     return;
   }
   if (trace_wps == 8) hipLaunchKernelGGL((traceq4_kernel<8, REL, LOG>), grid, block, c.lds_t, st, q);
@@ -511,17 +527,31 @@ void launch_traceq4_v(EzrtScene* s, const TraceCfg& c, const TraceQ4Args& q, hip
   else if (trace_wps == 6) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG>), grid, block, c.lds_t, st, q);
   else if (trace_wps == 4) hipLaunchKernelGGL((traceq4_kernel<4, REL, LOG>), grid, block, c.lds_t, st, q);
   else hipLaunchKernelGGL((traceq4_kernel<5, REL, LOG>), grid, block, c.lds_t, st, q);
-  s->n_trace_launches++;
 }
-template <bool REL>
+template <bool REL, bool GEN>
 void launch_traceq4_rel(EzrtScene* s, const TraceCfg& c, const TraceQ4Args& q, hipStream_t st) {
-  if (q.q.wave_log) launch_traceq4_v<REL, true>(s, c, q, st); // (debug_stages=2)
-  else launch_traceq4_v<REL, false>(s, c, q, st);
+  if (q.q.wave_log) launch_traceq4_v<REL, true, GEN>(s, c, q, st); // (debug_stages=2)
+  else launch_traceq4_v<REL, false, GEN>(s, c, q, st);
 }
 // t: the stage's queue arguments as for the binary kernel (knobs already filled); rel: 4-wide records translated by
 // t.origin (or NULL)
-void launch_traceq4_cfg(EzrtScene* s, const TraceCfg& c4, const TraceQArgs& t, const float4* rel, hipStream_t st) {
-  TraceQ4Args A;
+// gen (or NULL): the chunk's stage-0 arguments when the launch generates its primary rays itself (needs rel)
+void fill_traceq4_args(const EzrtScene* s, const TraceCfg& c4, const TraceQArgs& t, const float4* rel, const WfArgs* gen, TraceQ4Args& A) {
+  memset(&A.gen_p, 0, sizeof A.gen_p);
+  A.gen_blocks = nullptr;
+  A.gen_div_blocks = A.gen_div_sub = make_fastdiv(1u);
+  A.gen_scatter = 1u;
+  A.gen_scatter_shift = 6u;
+  A.gen_frame_first = 0u;
+  if (gen) {
+    A.gen_p = gen->p;
+    A.gen_blocks = gen->blocks;
+    A.gen_div_blocks = gen->div_blocks;
+    A.gen_div_sub = gen->div_sub;
+    A.gen_scatter = gen->scatter;
+    A.gen_scatter_shift = gen->scatter_shift;
+    A.gen_frame_first = gen->frame_first;
+  }
   A.q = t;
   A.q.stack_entries = (int32_t)(c4.lds / (BLOCK * sizeof(int)));
   A.q.lds_nodes = 0;
@@ -531,14 +561,18 @@ void launch_traceq4_cfg(EzrtScene* s, const TraceCfg& c4, const TraceQArgs& t, c
   A.root4 = s->root4;
   A.lds_nodes4 = c4.lds_nodes;
   {
-    // delta(ray) = (cz + cg max(M, |S|)) max |1/d|: twice the bound of ezrt_traceq4.h, constants rounded up
     const double eps = 1.0 / 16777216.0;
     A.prune_cs = __builtin_nextafterf((float)(2.0 * 17.0 * eps), __builtin_inff());
     A.prune_a = s->prune_a;
     A.stack_cap = (s->tune.debug_stack_cap > 0 && s->tune.debug_stack_cap < s->stack_need4) ? s->tune.debug_stack_cap : s->stack_need4;
   }
-  if (rel) launch_traceq4_rel<true>(s, c4, A, st);
-  else launch_traceq4_rel<false>(s, c4, A, st);
+}
+void launch_traceq4_cfg(EzrtScene* s, const TraceCfg& c4, const TraceQArgs& t, const float4* rel, hipStream_t st, const WfArgs* gen = nullptr) {
+  TraceQ4Args A;
+  fill_traceq4_args(s, c4, t, rel, gen, A);
+  if (rel && gen) launch_traceq4_rel<true, true>(s, c4, A, st);
+  else if (rel) launch_traceq4_rel<true, false>(s, c4, A, st);
+  else launch_traceq4_rel<false, false>(s, c4, A, st);
 }
 
 // schedule fields of a traceq launch that come from the knobs (clamped: ADVICE r1)
@@ -751,7 +785,11 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     pro.inner4_rel = pp.inner4_rel.p;
     pro.n_inner4 = s->n_inner4;
   }
-  hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((n_slots + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, a, pro);
+  // primary rays generated where they are consumed (primary_dir) when stage 0 runs the 4-wide kernel on eye-relative records
+  const bool gen_primary = wide && s->tune.rel_boxes && s->tune.gen_primary && !s->tune.packet;
+  a.gen_primary = 0u; // (the shading passes read the directions the trace launch stored: see traceq4_kernel GEN)
+  if (gen_primary) hipLaunchKernelGGL(chunk_prologue_kernel, dim3((unsigned)(4 * s->num_cus)), dim3(BLOCK), 0, st, a, pro);
+  else hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((n_slots + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, a, pro);
   if (s->tune.debug_stages && wide)
     fprintf(stderr, "[ezrt] traceq4 launches: %d stack rows (binary tree depth %d); primary stage %d workgroups/CU, %zu B LDS, %d records staged; "
             "bounce stages %d workgroups/CU, %zu B LDS, %d records staged\n", s->stack_need4, s->depth, cfg4_rel.blocks_per_cu, cfg4_rel.lds_t,
@@ -768,8 +806,71 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
   if (shade_grid > shade_grid_max) shade_grid = shade_grid_max;
 
   const int tail_from = (!full && !plog && !debug_stages && tu.tail_stage >= 2) ? tu.tail_stage : (1 << 30);
+  const int path_from = (!full && !plog && !debug_stages && !mis && wide && tu.path_stage >= 2) ? tu.path_stage : (1 << 30);
   for (int b = 0; b <= p->max_bounce; b++) {
     const int in = b & 1, out = in ^ 1;
+    if (b >= path_from && b < tail_from) { // every later bounce of the chunk in one persistent launch (pathq4_kernel)
+      a.rq_in = queue(in);
+      a.st_in = state(in);
+      a.n_in = pp.qcounts.p + b;
+      a.bounce = b;
+      // LDS: stack rows for the nearest-first traversal AND for the in-lane reference-order re-trace (binary depth), the
+      // lane table, then top-of-tree records; 4 workgroups per CU (the kernel is compiled for <= 128 VGPRs)
+      TraceCfg c;
+      const int rows = std::max(stack_rows4(s), s->depth + 1);
+      c.lds = (size_t)rows * BLOCK * sizeof(int);
+      const size_t lds_fixed = c.lds + BLOCK * sizeof(int);
+      size_t budget = (size_t)(158 * 1024) / 4;
+      budget -= budget / 16;
+      int nrec = budget > lds_fixed ? (int)((budget - lds_fixed) / (N4_LDS_DWORDS * 4)) : 0;
+      nrec = std::min(nrec, std::min(s->n_inner4, tu.lds_nodes));
+      c.lds_nodes = nrec < 0 ? 0 : nrec;
+      c.lds_t = lds_fixed + (size_t)c.lds_nodes * (N4_LDS_DWORDS * 4);
+      c.blocks_per_cu = 4;
+      c.grid_full = (unsigned)(s->num_cus * 4);
+      TraceQArgs t;
+      t.sc = trace_scene(a.sc);
+      t.rq = queue(in);
+      t.hits = pp.hits2[in].p;
+      t.n_paths = pp.qcounts.p + b;
+      t.rays_per_path = 1u;
+      t.const_origin = 0u;
+      t.inner_rel = nullptr;
+      t.origin[0] = t.origin[1] = t.origin[2] = 0.0f;
+      t.head = pp.qheads.p + (size_t)b * HEAD_SLOT;
+      t.counters = s->counters.p;
+      fill_trace_knobs(s, c, t);
+      if (tu.path_refill_min > 0) t.refill_min = (uint32_t)tu.path_refill_min; // (a finished lane waits for the batch before it is shaded)
+      t.dbg = nullptr;
+      t.slot_map = nullptr;
+      t.steal = 0u;
+      t.count_rays = 1u;
+      t.redo_count = pp.qcounts.p + 128 + b;
+      t.redo_slots = pp.redo_slots.p;
+      t.redo_flag = pp.redo_flag.p;
+      t.force_pending = (uint32_t)tu.debug_force_pending;
+      t.wave_log = nullptr;
+      TraceQ4Args A;
+      fill_traceq4_args(s, c, t, nullptr, nullptr, A);
+      const bool pr = prune_mode(s) != 0;
+      const dim3 grid(c.grid_full), block(BLOCK);
+      switch (p->integrator) {
+        case EZRT_INTEGRATOR_P3_DIFFUSE:
+          if (pr) hipLaunchKernelGGL((pathq4_kernel<EZRT_INTEGRATOR_P3_DIFFUSE, 2>), grid, block, c.lds_t, st, A, a);
+          else hipLaunchKernelGGL((pathq4_kernel<EZRT_INTEGRATOR_P3_DIFFUSE, 0>), grid, block, c.lds_t, st, A, a);
+          break;
+        case EZRT_INTEGRATOR_P4_DISNEY:
+          if (pr) hipLaunchKernelGGL((pathq4_kernel<EZRT_INTEGRATOR_P4_DISNEY, 2>), grid, block, c.lds_t, st, A, a);
+          else hipLaunchKernelGGL((pathq4_kernel<EZRT_INTEGRATOR_P4_DISNEY, 0>), grid, block, c.lds_t, st, A, a);
+          break;
+        default:
+          if (pr) hipLaunchKernelGGL((pathq4_kernel<EZRT_INTEGRATOR_P5_SOBOL, 2>), grid, block, c.lds_t, st, A, a);
+          else hipLaunchKernelGGL((pathq4_kernel<EZRT_INTEGRATOR_P5_SOBOL, 0>), grid, block, c.lds_t, st, A, a);
+          break;
+      }
+      s->n_trace_launches++;
+      break;
+    }
     if (b >= tail_from) { // the few paths still alive finish here, one lane each
       a.rq_in = queue(in);
       a.st_in = state(in);
@@ -857,7 +958,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     } else {
       if (wide) {
         const bool rel = b == 0 && tu.rel_boxes;
-        launch_traceq4_cfg(s, rel ? cfg4_rel : cfg4_abs, t, rel ? pp.inner4_rel.p : nullptr, st);
+        launch_traceq4_cfg(s, rel ? cfg4_rel : cfg4_abs, t, rel ? pp.inner4_rel.p : nullptr, st, (rel && gen_primary) ? &a : nullptr);
       }
       else launch_traceq(t);
       if (t.steal || wide) { // rays that met an exact distance tie, or (4-wide) are not tame -- normally none: reference order, plain stores
@@ -907,6 +1008,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
       g.div_blocks = a.div_blocks;
       g.div_sub = a.div_sub;
       g.width = p->width;
+      g.p = *p;
       g.log_slots = 1 + 2 * p->max_bounce;
       g.log_tri = plog->tri;
       g.log_t = plog->t;

@@ -67,6 +67,58 @@ EZD unsigned long long wave_sum(uint32_t v) {
   return s;
 }
 
+// ---- queue position -> pixel-sample -> primary ray (used by raygen_kernel, and by the primary stage's trace and shading
+// kernels when the chunk's rays are generated where they are consumed: Tuning::gen_primary)
+EZD void slot_to_pixel(const int2* blocks, const FastDiv& n_blocks, uint32_t slot, uint32_t frame_first, int& x, int& y,
+                       uint32_t& frame) {
+  uint32_t tid = slot & 255u;
+  uint32_t b = slot >> 8;
+  const uint32_t fk = fastdiv(b, n_blocks), blk = b - fk * n_blocks.d;
+  int2 org = blocks[blk];
+  uint32_t wave = tid >> 6, lane = tid & 63u;
+  x = org.x + (int)((wave & 1u) * 8u + (lane & 7u));
+  y = org.y + (int)((wave >> 1) * 8u + (lane >> 3));
+  frame = frame_first + fk;
+}
+
+// Queue order of the primary rays.  Sample slots are laid out [frame][16x16 block][8x8 sub-block]
+// [lane]; taking queue position = sample slot would hand a wave pools of 256 rays from ONE 16x16
+// pixel block -- all cheap (sky) or all expensive (the Bunny), and the launch ends with the waves
+// that drew the expensive ones.  So the 8x8 sub-blocks of a frame are visited in a scattered
+// order, sub-block (r * scatter) mod n_sub at position r (scatter ~ 2531, coprime to n_sub): a pool is four
+// sub-blocks from distant parts of the image and every pool costs about the same.
+EZD uint32_t queue_to_sample(uint32_t qslot, const FastDiv& n_sub_div, uint32_t scatter, uint32_t sh = 6u) {
+  const uint32_t n_sub = n_sub_div.d; // granules of 1 << sh slots per frame = (n_blocks * 256) >> sh
+  const uint32_t q = qslot >> sh;
+  const uint32_t fk = fastdiv(q, n_sub_div), r = q - fk * n_sub;
+  const uint32_t p = r * scatter; // 32-bit: the host keeps n_sub <= 2^20 and scatter < 2^12 here
+  const uint32_t r2 = p - fastdiv(p, n_sub_div) * n_sub;
+  return ((fk * n_sub + r2) << sh) | (qslot & ((1u << sh) - 1u));
+}
+
+// The primary ray of queue position `qslot`: main() up to the hitBVH call (P5/fsh:315-318 seed, 920-925 jitter, camera,
+// normalize) -- (dir.xyz, 1), or w = 0 for a pixel this shard does not own.  ONE definition for every kernel that needs the
+// direction, so that the ray the trace follows and the ray the shading stage shades are the same bits.
+EZD float4 primary_dir(const EzrtRenderParams& p, const int2* blocks, const FastDiv& div_blocks, const FastDiv& div_sub, uint32_t scatter,
+                       uint32_t scatter_shift, uint32_t frame_first, uint32_t qslot) {
+  int x, y;
+  uint32_t frame;
+  slot_to_pixel(blocks, div_blocks, queue_to_sample(qslot, div_sub, scatter, scatter_shift), frame_first, x, y, frame);
+  if (!pixel_owned(p, x, y)) return make_float4(0, 0, 0, 0.0f);
+  const uint32_t ix = (uint32_t)x, iy = (uint32_t)y;
+  uint32_t seed = (ix * 1973u + iy * 9277u + frame * 26699u) | 1u;
+  const float W = (float)p.width, H = (float)p.height;
+  float pixx = ((float)ix + 0.5f) / W * 2.0f - 1.0f;
+  float pixy = ((float)iy + 0.5f) / H * 2.0f - 1.0f;
+  float aax = (rnd(seed) - 0.5f) / W;
+  float aay = (rnd(seed) - 0.5f) / H;
+  float vx = pixx + aax, vy = pixy + aay, vz = -1.5f;
+  const float* m = p.camera_rotate;
+  f3 dir = mk(m[0] * vx + m[4] * vy + m[8] * vz, m[1] * vx + m[5] * vy + m[9] * vz, m[2] * vx + m[6] * vy + m[10] * vz);
+  dir = normalize(dir);
+  return make_float4(dir.x, dir.y, dir.z, 1.0f);
+}
+
 template <bool PATHLOG>
 EZD void plog(const TraceArgs& a, size_t pix, int slot, int32_t tri, float t) {
   if (PATHLOG) {

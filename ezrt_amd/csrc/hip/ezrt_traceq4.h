@@ -65,6 +65,11 @@ struct TraceQ4Args {
   int32_t lds_nodes4;       // records [0, lds_nodes4) staged in LDS
   // PRUNE > 0 (see "Distance pruning" below): delta(ray) = (prune_a + prune_cs * |S|_inf) * max_k |1/d_k|
   float prune_a, prune_cs;
+  // GEN (primary stage only): the queue holds no directions; the ray of queue position q is primary_dir(gen_*, q)
+  EzrtRenderParams gen_p;
+  const int2* gen_blocks;
+  FastDiv gen_div_blocks, gen_div_sub;
+  uint32_t gen_scatter, gen_scatter_shift, gen_frame_first;
   int32_t stack_cap;        // PRUNE == 2: live stack rows beyond which a ray is handed to the redo list (the launch
                             // allocates stack_cap + 3 rows: one step pushes at most three)
 };
@@ -153,8 +158,27 @@ EZD void chunk_prologue(const ChunkPrologue& g, uint32_t tid, uint32_t n_threads
 // LOG: the per-wave diagnostics of debug_stages=2 (a.wave_log).  A template parameter, not a run-time test: the
 // counters and time stamps are loop-carried values, and even never-executed they cost the production kernel registers
 // (one 64-bit time stamp turned 4 spills into 7: -2 %).
-template <int WPS, bool REL, bool LOG = false, int PRUNE = 0>
-__global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
+// GEN (with REL): primary rays are generated in the refill block -- seed, AA jitter, camera rotation, normalize:
+// primary_dir, the code raygen_kernel runs -- and stored to the queue from here (the stage's shading passes and a redo
+// launch read them there: recomputing the direction in the shading kernels cost them 30 us each on C2, more than the
+// 16-byte read).  What goes away is raygen_kernel's launch and this kernel's read of the queue: the stores ride on a
+// memory system the VALU-bound traversal leaves idle.
+//
+// Hook: what happens to a lane whose ray is finished.  NoPathHook (traceq4_kernel): the hit record is published and the
+// lane takes the next ray of the queue.  A path hook (pathq4_kernel, ezrt_wavefront.h) shades the hit IN the refill block
+// and hands the lane the path's next ray, so that the small late bounces of a chunk are ONE launch whose length is the
+// longest path's, not one launch per bounce each as long as its deepest ray; exact ties and rays that are not tame are
+// then re-traced in the reference's order by the lane itself (hook.retrace), and there is no stealing (a split ray
+// would need a completion count before it can be shaded).
+struct NoPathHook {
+  static constexpr bool PATH = false;
+  EZD void retrace(f3, f3, int*, int32_t&, float&) const {}
+  EZD bool shade(uint32_t, f3&, f3&, int32_t, float, int&) const { return false; }
+  EZD int first_bounce() const { return 0; }
+};
+template <bool REL, bool LOG, int PRUNE, bool GEN, class Hook>
+EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
+  static_assert(!GEN || REL, "generated rays start at the launch's uniform origin");
   extern __shared__ __attribute__((aligned(16))) int lds_stack[];
   const TraceQArgs& a = A.q;
   // LDS layout: [lane table: BLOCK ints][stack rows][staged records]
@@ -193,6 +217,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
   bool shared = false;
   uint32_t ref = REF_NONE;
   uint32_t n_counted = 0;
+  int bl = 0; // (Hook::PATH) the bounce this lane's path is in
   unsigned long long* hits64 = reinterpret_cast<unsigned long long*>(a.hits);
   // PRUNE: a slot is skipped when its entry distance exceeds prune_t = (best_t + pdelta)(1 + 2^-19),
   //   pdelta = (prune_a + prune_cs |S|_inf) max_k |inv_k|
@@ -251,8 +276,28 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
     const unsigned long long wantm = ballot(want);
     if (wantm && ((uint32_t)__popcll(wantm) >= a.refill_min || !ballot(ref < REF_DONE))) {
       if (LOG && a.wave_log) dbg_refills++;
-      if (ref == REF_DONE) publish();
-      if (want && nx_slot != REF_NONE) {
+      if (Hook::PATH) {
+        if (ref == REF_DONE) {
+          if (tie) hook.retrace(S, d, stack, best_tri, best_t); // exact tie / not tame: the reference's order, in this lane
+          tie = false;
+          if (hook.shade(slot, S, d, best_tri, best_t, bl)) { // the path goes on: S, d = its next ray
+            n_counted += a.count_rays;
+            inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            best_t = INF;
+            best_tri = -1;
+            sp = 0;
+            sb = 0;
+            tie = !ray_is_tame(S, inv);
+            ref = tie ? REF_DONE : A.root4; // (a ray that is not tame is "finished" at once and re-traced at the next refill)
+            if (PRUNE) set_delta();
+          } else {
+            ref = REF_NONE;
+          }
+        }
+      } else if (ref == REF_DONE) {
+        publish();
+      }
+      if (ref == REF_NONE && nx_slot != REF_NONE) {
         const uint32_t adopted = nx_slot;
         nx_slot = REF_NONE;
         if (nx_d.w != 0.0f) {
@@ -272,6 +317,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
           tie = !ray_is_tame(S, inv) || (a.force_pending && adopted % a.force_pending == 0u);
           ref = tie ? REF_DONE : A.root4;
           best_tri = tie ? HIT_PENDING : -1;
+          if (Hook::PATH) bl = hook.first_bounce();
           if (PRUNE) set_delta();
         }
       }
@@ -314,7 +360,12 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
           if (a.slot_map) rs = a.slot_map[idx];
           nx_slot = rs;
           if (!REL) nx_o = a.const_origin == 1u ? make_float4(a.origin[0], a.origin[1], a.origin[2], 0.0f) : a.rq.o[rs >> (a.const_origin >> 1)];
-          nx_d = a.rq.d[rs];
+          if (GEN) { // generate, and leave the direction in the queue for the stage's shading passes (and a redo launch)
+            nx_d = primary_dir(A.gen_p, A.gen_blocks, A.gen_div_blocks, A.gen_div_sub, A.gen_scatter, A.gen_scatter_shift, A.gen_frame_first, rs);
+            a.rq.d[rs] = nx_d;
+          } else {
+            nx_d = a.rq.d[rs];
+          }
         }
       }
     }
@@ -617,6 +668,11 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
     w[6] = dbg_refills | ((unsigned long long)dbg_steals << 32);
     w[7] = t_exhausted;
   }
+}
+
+template <int WPS, bool REL, bool LOG = false, int PRUNE = 0, bool GEN = false>
+__global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
+  traceq4_body<REL, LOG, PRUNE, GEN>(A, NoPathHook());
 }
 
 } // namespace ezd

@@ -74,34 +74,8 @@ struct WfArgs {
   FastDiv div_sub;         // division by the queue granules per frame, (n_blocks * 256) >> scatter_shift
   uint32_t scatter;        // queue order of the primary rays: see queue_to_sample (1 = identity)
   uint32_t scatter_shift;  // scattered granule = 1 << scatter_shift slots (6: 8x8 sub-block, 8: 16x16 block, 5: 8x4 pixels)
+  uint32_t gen_primary;    // 1: queue 0 holds no directions -- stage 0 recomputes its ray from the queue position (primary_dir)
 };
-
-EZD void slot_to_pixel(const int2* blocks, const FastDiv& n_blocks, uint32_t slot, uint32_t frame_first, int& x, int& y,
-                       uint32_t& frame) {
-  uint32_t tid = slot & 255u;
-  uint32_t b = slot >> 8;
-  const uint32_t fk = fastdiv(b, n_blocks), blk = b - fk * n_blocks.d;
-  int2 org = blocks[blk];
-  uint32_t wave = tid >> 6, lane = tid & 63u;
-  x = org.x + (int)((wave & 1u) * 8u + (lane & 7u));
-  y = org.y + (int)((wave >> 1) * 8u + (lane >> 3));
-  frame = frame_first + fk;
-}
-
-// Queue order of the primary rays.  Sample slots are laid out [frame][16x16 block][8x8 sub-block]
-// [lane]; taking queue position = sample slot would hand a wave pools of 256 rays from ONE 16x16
-// pixel block -- all cheap (sky) or all expensive (the Bunny), and the launch ends with the waves
-// that drew the expensive ones.  So the 8x8 sub-blocks of a frame are visited in a scattered
-// order, sub-block (r * scatter) mod n_sub at position r (scatter ~ 2531, coprime to n_sub): a pool is four
-// sub-blocks from distant parts of the image and every pool costs about the same.
-EZD uint32_t queue_to_sample(uint32_t qslot, const FastDiv& n_sub_div, uint32_t scatter, uint32_t sh = 6u) {
-  const uint32_t n_sub = n_sub_div.d; // granules of 1 << sh slots per frame = (n_blocks * 256) >> sh
-  const uint32_t q = qslot >> sh;
-  const uint32_t fk = fastdiv(q, n_sub_div), r = q - fk * n_sub;
-  const uint32_t p = r * scatter; // 32-bit: the host keeps n_sub <= 2^20 and scatter < 2^12 here
-  const uint32_t r2 = p - fastdiv(p, n_sub_div) * n_sub;
-  return ((fk * n_sub + r2) << sh) | (qslot & ((1u << sh) - 1u));
-}
 
 // ---------------------------------------------------------------------------
 // raygen: P5/fsh:315-318, 920-925
@@ -113,29 +87,21 @@ __global__ __launch_bounds__(BLOCK) void raygen_kernel(WfArgs a, ChunkPrologue g
   if (blockIdx.x == 0) // the chunk's Sobol table (read by the shading stages): sobol(d, grayCode(frame + 1)), 16 dims per frame
     for (uint32_t k = threadIdx.x; k < a.n_frames * 16u; k += BLOCK)
       a.sobol_out[k] = sobol(k & 15u, gray_code(a.frame_first + (k >> 4) + 1u));
-  int x, y;
-  uint32_t frame;
-  slot_to_pixel(a.blocks, a.div_blocks, queue_to_sample(slot, a.div_sub, a.scatter, a.scatter_shift), a.frame_first, x, y, frame);
-  const EzrtRenderParams& p = a.p;
-  if (!pixel_owned(p, x, y)) {
-    a.rq_out.d[slot] = make_float4(0, 0, 0, 0.0f);
-    return;
-  }
-  const uint32_t ix = (uint32_t)x, iy = (uint32_t)y;
-  uint32_t seed = (ix * 1973u + iy * 9277u + frame * 26699u) | 1u;
-  const float W = (float)p.width, H = (float)p.height;
-  float pixx = ((float)ix + 0.5f) / W * 2.0f - 1.0f;
-  float pixy = ((float)iy + 0.5f) / H * 2.0f - 1.0f;
-  float aax = (rnd(seed) - 0.5f) / W;
-  float aay = (rnd(seed) - 0.5f) / H;
-  float vx = pixx + aax, vy = pixy + aay, vz = -1.5f;
-  const float* m = p.camera_rotate;
-  f3 dir = mk(m[0] * vx + m[4] * vy + m[8] * vz, m[1] * vx + m[5] * vy + m[9] * vz, m[2] * vx + m[6] * vy + m[10] * vz);
-  dir = normalize(dir);
   // only the direction is stored: every primary ray starts at the eye (the trace takes it from its
   // arguments) and the shading stage re-derives the RNG state from the slot (two hashes) -- 32 B per
   // pixel-sample less to write here and 48 B less to read downstream
-  a.rq_out.d[slot] = make_float4(dir.x, dir.y, dir.z, 1.0f);
+  a.rq_out.d[slot] = primary_dir(a.p, a.blocks, a.div_blocks, a.div_sub, a.scatter, a.scatter_shift, a.frame_first, slot);
+}
+
+// The chunk's housekeeping alone, for chunks whose primary rays are generated where they are consumed (gen_primary):
+// Sobol table, zeroed queue heads and stage counters, the eye-relative records, stage 0's path count.
+__global__ __launch_bounds__(BLOCK) void chunk_prologue_kernel(WfArgs a, ChunkPrologue g) {
+  const uint32_t tid = blockIdx.x * BLOCK + threadIdx.x;
+  chunk_prologue(g, tid, gridDim.x * BLOCK);
+  if (tid == 0) *a.n_out = a.n_slots;
+  if (blockIdx.x == 0)
+    for (uint32_t k = threadIdx.x; k < a.n_frames * 16u; k += BLOCK)
+      a.sobol_out[k] = sobol(k & 15u, gray_code(a.frame_first + (k >> 4) + 1u));
 }
 
 // ---------------------------------------------------------------------------
@@ -229,7 +195,9 @@ EZD void shade_load(const WfArgs& a, const uint32_t i, const bool live, ShadeIn&
   // round trip) instead of discovering them one branch at a time
   const uint32_t ii = live ? i : 0u;
   const uint32_t rslot = (b == 0 || !MIS) ? ii : (2u * ii + 1u);
-  float4 rd4 = a.rq_in.d[rslot];
+  float4 rd4;
+  if (B0 && a.gen_primary) rd4 = primary_dir(a.p, a.blocks, a.div_blocks, a.div_sub, a.scatter, a.scatter_shift, a.frame_first, rslot);
+  else rd4 = a.rq_in.d[rslot];
   const bool from_entry = PASS == 2 && entry && (int32_t)entry->y != HIT_PENDING && (!MIS || (int32_t)entry->w != HIT_PENDING);
   int2 h = from_entry ? make_int2((int32_t)entry->y, (int32_t)entry->z) : a.hits[rslot];
   float4 ro4 = make_float4(p.eye[0], p.eye[1], p.eye[2], 0.0f);
@@ -281,14 +249,15 @@ EZD void shade_load(const WfArgs& a, const uint32_t i, const bool live, ShadeIn&
 }
 
 // `i` is only used by stage 0 (queue position -> sample slot)
+// b_lane (>= 0): the bounce index of THIS path when the kernel's paths are not all at a.bounce (pathq4_kernel)
 template <int INTEG, bool FULLCTR, int PASS, int STAGE>
 EZD bool shade_body(const WfArgs& a, const uint32_t i, bool live, const ShadeIn& in, Counters& ctr, uint32_t& n_samples,
-                    ShadeOut& o) {
+                    ShadeOut& o, const int b_lane = -1) {
   constexpr bool P5TRI = (INTEG >= 50);
   constexpr bool MIS = integ_mis<INTEG>();
   const DevScene& sc = a.sc;
   const EzrtRenderParams& p = a.p;
-  const int b = a.bounce;
+  const int b = b_lane >= 0 ? b_lane : a.bounce;
   constexpr bool B0 = (STAGE == 0);
   constexpr bool COMPACT = compact_state<INTEG>();
   uint32_t sslot = 0, seed = 0, flags = 0, tri0 = 0;
@@ -707,6 +676,71 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_kernel(WfArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// pathq4_kernel: the bounces >= a.bounce of a chunk as ONE persistent launch (integrators without MIS: one ray per path).
+//
+// After two stages only a few per cent of a chunk's paths are alive (C2: 0.7 M of 16.8 M enter stage 2) and a stage costs
+// its fixed price, not its work: a trace launch lasts as long as its DEEPEST ray (iterations of ~2-3 us each, whatever the
+// queue holds), then a redo launch, then a shading launch, each behind a launch gap -- stages 2-4 were 450 of C2's 2200 us
+// for 4 % of its rays.  Here the traversal is traceq4_body itself (4-wide records, pruning, cooperative leaves, prefetched
+// refill); a lane whose ray is finished is shaded in the refill block by the staged kernels' own shade_body and continues
+// with the path's next ray, its state parked in the stage's state arrays at the path's queue index.  One launch, one tail:
+// the longest PATH.  Exact ties and rays that are not tame are re-traced by the lane in the reference's order (hit_bvh).
+// Same arithmetic per path as the staged kernels, so the same samples; rays are counted into the same counter.
+// MEASURED (C2, profiles/r3/path_kernel_negative.txt): NOT faster -- 800-1000 us against the staged stages' 450 us.  The
+// premise fails: the longest path is about the SUM of the stages' deepest rays (a path in a concavity of the Bunny stays
+// deep bounce after bounce), and each shading batch stalls the live traversals of its wave for its chain of dependent
+// loads.  Off by default (Tuning::path_stage), kept with its tests as the measured end of that idea.
+template <int INTEG>
+struct PathHook {
+  static constexpr bool PATH = true;
+  const WfArgs& w;
+  EZD int first_bounce() const { return w.bounce; }
+  EZD void retrace(f3 S, f3 d, int* stack, int32_t& best_tri, float& best_t) const {
+    Counters dummy = {0, 0, 0, 0, 0, 0, 0};
+    hit_bvh<false, BLOCK>(w.sc, S, d, stack, best_tri, best_t, dummy);
+  }
+  // slot: the path's index in the stage's queue = where its state lives.  Returns true if the path goes on (S, d = next ray).
+  EZD bool shade(uint32_t slot, f3& S, f3& d, int32_t best_tri, float best_t, int& bl) const {
+    constexpr bool COMPACT = compact_state<INTEG>();
+    ShadeIn in;
+    in.rd4 = make_float4(d.x, d.y, d.z, 1.0f);
+    in.ro4 = make_float4(S.x, S.y, S.z, 0.0f);
+    in.s0 = w.st_in.s0[slot];
+    in.s1 = w.st_in.s1[slot];
+    in.s2 = w.st_in.s2[slot];
+    in.s3 = COMPACT ? make_float4(0, 0, 0, 0) : w.st_in.s3[slot];
+    in.s4 = make_float4(0, 0, 0, 0);
+    in.h = make_int2(best_tri, __float_as_int(best_t));
+    in.sh = make_int2(-1, 0);
+    Counters ctr = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t ns = 0;
+    ShadeOut o;
+    shade_body<INTEG, false, 0, 2>(w, slot, true, in, ctr, ns, o, bl);
+    if (!o.emit) return false;
+    if (COMPACT) {
+      w.st_in.s0[slot] = make_float4(o.history.x, o.history.y, o.history.z, o.cosine);
+      w.st_in.s1[slot] = make_float4(o.Lo.x, o.Lo.y, o.Lo.z, __uint_as_float(o.sslot));
+      w.st_in.s2[slot] = make_float4(o.f_r.x, o.f_r.y, o.f_r.z, __uint_as_float(o.tri0));
+    } else {
+      w.st_in.s0[slot] = make_float4(o.history.x, o.history.y, o.history.z, o.cosine);
+      w.st_in.s1[slot] = make_float4(o.Lo.x, o.Lo.y, o.Lo.z, o.pdf);
+      w.st_in.s2[slot] = make_float4(o.f_r.x, o.f_r.y, o.f_r.z, __uint_as_float(o.sslot));
+      w.st_in.s3[slot] = make_float4(o.Le0.x, o.Le0.y, o.Le0.z, __uint_as_float(o.seed));
+    }
+    S = o.P;
+    d = o.rayL;
+    bl++;
+    return true;
+  }
+};
+template <int INTEG, int PRUNE>
+__global__ __launch_bounds__(BLOCK, 4) void pathq4_kernel(TraceQ4Args A, WfArgs W) {
+  static_assert(!integ_mis<INTEG>(), "one ray per path");
+  const PathHook<INTEG> hook{W};
+  traceq4_body<false, false, PRUNE, false>(A, hook);
+}
+
+// ---------------------------------------------------------------------------
 // tail_kernel: everything after stage `a.bounce` for the paths of its queue, one lane per path.
 //
 // After two or three stages only a few per cent of the paths are alive (C2: 0.7 M of 16.8 M enter stage 2), and
@@ -807,6 +841,7 @@ struct PathLogArgs {
   uint32_t frame_first;
   uint32_t scatter, scatter_shift;
   int32_t width, log_slots;
+  EzrtRenderParams p;    // (pixel ownership of stage 0)
   int32_t* log_tri;
   float* log_t;
   float* log_colour;     // pathcolour_kernel
@@ -829,7 +864,7 @@ __global__ __launch_bounds__(BLOCK) void pathlog_kernel(PathLogArgs a) {
     a.log_t[pix * a.log_slots + slot] = h.x >= 0 ? __int_as_float(h.y) : INF;
   };
   if (a.bounce == 0) {
-    if (a.rq_d[i].w == 0.0f) return; // pixel not owned by this shard: the caller's values stay
+    if (!pixel_owned(a.p, x, y)) return; // pixel not owned by this shard: the caller's values stay
     for (int k = 0; k < a.log_slots; k++) {
       a.log_tri[pix * a.log_slots + k] = -2;
       a.log_t[pix * a.log_slots + k] = INF;

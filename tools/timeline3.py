@@ -3,7 +3,7 @@ previous kernel's end (us), queue -- from a rocprofv3 --kernel-trace CSV of benc
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'raygen' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'raygen' in r['Kernel_Name'] or 'chunk_prologue' in r['Kernel_Name']]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else -4
 i0, i1 = idx[k], idx[k + 2]
 t0 = int(rows[i0]['Start_Timestamp']); prev_end = t0
