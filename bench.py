@@ -70,13 +70,20 @@ def physical_roofline(trace_ms_per_step, launches_per_step):
     """Counters of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r2/pmc_summary.json, made by
     tools/profile.sh + tools/summarize_profile.py), combined with THIS run's launch durations.  The profile is stamped
     with a hash of the GPU sources; a stale stamp means the counters describe other code and nothing is quoted."""
-    path = os.path.join(ROOT, "profiles", "r2", "pmc_summary.json")
-    if not os.path.exists(path):
-        return None, "no profiles/r2/pmc_summary.json"
     from ezrt_amd.srchash import gpu_source_hash
-    pm = json.load(open(path))
-    if pm.get("source_sha") != gpu_source_hash():
-        return None, "profiles/r2/pmc_summary.json is stale (GPU sources changed since it was collected)"
+    sha = gpu_source_hash()
+    pm, path, seen = None, None, []
+    for rnd in sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r")), reverse=True):
+        cand = os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")
+        if os.path.exists(cand):
+            seen.append("profiles/%s/pmc_summary.json" % rnd)
+            got = json.load(open(cand))
+            if got.get("source_sha") == sha:
+                pm, path = got, "profiles/%s/pmc_summary.json" % rnd
+                break
+    if pm is None:
+        return None, ("no pmc_summary.json under profiles/" if not seen else
+                      "%s: stale (GPU sources changed since they were collected: %s)" % (", ".join(seen), sha))
     k = pm["dominant"]                      # per STEP sums over the dominant kernel's launches
     secs = trace_ms_per_step * 1e-3
     insts = k["SQ_INSTS_VALU"]
@@ -95,7 +102,7 @@ def physical_roofline(trace_ms_per_step, launches_per_step):
         "l2_frac": round(k["l2_bytes"] / secs / 1e9 / L2_PEAK_GBS, 4),
         "lds_bytes_per_step": int(k["lds_bytes"]),
         "lds_frac": round(k["lds_bytes"] / secs / 1e9 / LDS_PEAK_GBS, 4),
-        "source": "profiles/r2/pmc_summary.json @ %s" % pm["source_sha"],
+        "source": "%s @ %s" % (path, pm["source_sha"]),
     }
     out["traffic_per_launch"] = int(k["hbm_bytes"] / max(1, launches_per_step))
     return out, None
@@ -417,6 +424,9 @@ def main():
             "ratio_vs_measured_copy_peak_6290": round(ach / 6290.0, 4),
             "alg_bytes_per_launch": int(bytes_trace // launches), "alg_bytes_per_ray": round(bytes_trace / c["rays"], 1),
             "counters_per_step": {k: c[k] for k in ("rays", "node_pops", "inner_pops", "tri_tests", "mat_fetch", "samples", "env_map", "env_cache")},
+            "counters_from": "one extra, untimed step with ezrt_set_instrumentation(1): the binary in-order kernel traceq_kernel<true,6> counts "
+                             "the REFERENCE's unpruned traversal (P, I, T, M of SURVEY 8(d)) -- not the timed 4-wide, pruning kernel, which "
+                             "visits fewer boxes by construction",
             "whole_step": {"alg_bytes": int(bytes_step), "gpu_ms": round(ms_total, 4),
                            "achieved_GBs": round(bytes_step / (ms_total * 1e-3) / 1e9, 2)}}
         out["roofline"] = rf

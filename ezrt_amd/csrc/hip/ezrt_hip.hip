@@ -122,6 +122,8 @@ struct Tuning {
                            // written to a queue by raygen_kernel (timed pipeline with the 4-wide, eye-relative records only)
   int prune = 2;           // traceq4_kernel's distance pruning (ezrt_traceq4.h "Distance pruning": proven results-neutral): 0 the
                            // reference's unpruned traversal, 1 skip slots provably beyond the best hit, 2 that + nearest slot first
+  int prune_mis = 2;       // ... of the MIS integrators' bounce stages (two rays per path, one an env shadow ray) when prune == 2:
+                           // slot order there (1) was a wash on C4 (14.36 vs 14.28 Grays/s) and lost 6 % on C5 (2.46 vs 2.61)
   int prune_min_records = 0; // scenes with fewer 4-wide records than this are traced unpruned (small trees gain nothing)
   int debug_stack_cap = 0; // test hook (prune 2): > 0 = stack rows beyond which a ray goes to the redo list, instead of the scene's bound
   int audit_via_queue = 0; // 1: ezrt_query_hits and ezrt_render_paths run through the TIMED kernels (traceq_kernel with
@@ -167,6 +169,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"gen_primary", &Tuning::gen_primary, 0, 1},
                               {"rel_min_records", &Tuning::rel_min_records, 0, 4096},
                               {"prune", &Tuning::prune, 0, 2},
+                              {"prune_mis", &Tuning::prune_mis, 0, 2},
                               {"prune_min_records", &Tuning::prune_min_records, 0, 1 << 24},
                               {"debug_stack_cap", &Tuning::debug_stack_cap, 0, 64},
                               {"audit_via_queue", &Tuning::audit_via_queue, 0, 2}};
@@ -508,7 +511,9 @@ template <bool REL, bool LOG, bool GEN>
 void launch_traceq4_v(EzrtScene* s, const TraceCfg& c, const TraceQ4Args& q, hipStream_t st) {
   const int trace_wps = wps4(s, REL);
   const dim3 grid(c.grid_full), block(BLOCK);
-  const int prune = prune_mode(s);
+  int prune = prune_mode(s);
+  // (knob prune_mis: another order for the launches whose queue holds env shadow rays -- measured, not better)
+  if (prune == 2 && q.q.rays_per_path == 2u && s->tune.prune_mis != 2) prune = s->tune.prune_mis;
   s->n_trace_launches++;
   if (prune || GEN) { // (these variants exist for the two register budgets the launches use: 7 and 6 waves per SIMD)
     if (trace_wps >= 7) {

@@ -1,6 +1,6 @@
 """tools/config_one.py C5 [spp]: one BASELINE config on one GPU, rays/s (knobs through EZRT_* env variables)."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ezrt_amd import scene as S, scenes, trace
 hip = trace.hip()

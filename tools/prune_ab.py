@@ -1,7 +1,7 @@
 """tools/prune_ab.py C2 C3 C5 ...: the distance-pruning modes of traceq4_kernel side by side on one GPU -- rays/s per mode, the
 frames compared on the bits (a schedule knob must never change them), the scene's pruning bound."""
 import json, sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ezrt_amd import scene as S, scenes, trace
 hip = trace.hip()
