@@ -37,6 +37,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver of this pool only supports dmabuf IPC: without this RCCL's device-memory sharing across the ranks of a
+# node fails with `hipIpcGetMemHandle: invalid argument` (already exported on the boxes; kept for any other launcher)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 L2_PEAK_GBS = 34500.0        # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
