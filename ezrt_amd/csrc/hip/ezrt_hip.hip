@@ -120,6 +120,8 @@ struct Tuning {
   int rel_min_records = 24; // the primary stage runs at trace_wps_rel waves per SIMD only while that leaves this many top-of-tree records in LDS
   int gen_primary = 1;     // primary rays are generated inside the primary stage's trace and shading kernels (primary_dir) instead of
                            // written to a queue by raygen_kernel (timed pipeline with the 4-wide, eye-relative records only)
+  int retree = 1;          // READ AT SCENE CREATION (EZRT_RETREE): the 4-wide records are built over a binned-SAH tree of the
+                           // reference's LEAVES instead of over a cut of the reference's own inner nodes (retree_leaves below)
   int prune = 2;           // traceq4_kernel's distance pruning (ezrt_traceq4.h "Distance pruning": proven results-neutral): 0 the
                            // reference's unpruned traversal, 1 skip slots provably beyond the best hit, 2 that + nearest slot first
   int prune_mis = 2;       // ... of the MIS integrators' bounce stages (two rays per path, one an env shadow ray) when prune == 2:
@@ -168,6 +170,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"debug_oom_above", &Tuning::debug_oom_above, 0, 1 << 30},
                               {"gen_primary", &Tuning::gen_primary, 0, 1},
                               {"rel_min_records", &Tuning::rel_min_records, 0, 4096},
+                              {"retree", &Tuning::retree, 0, 1},
                               {"prune", &Tuning::prune, 0, 2},
                               {"prune_mis", &Tuning::prune_mis, 0, 2},
                               {"prune_min_records", &Tuning::prune_min_records, 0, 1 << 24},
@@ -226,6 +229,7 @@ struct EzrtScene {
   int n_inner4 = 0;
   int stack_need4 = 1;        // LDS stack rows the 4-wide traversal can need (exact worst case over hit patterns)
   // distance pruning (ezrt_traceq4.h): scene maxima of the per-triangle bound, evaluated in double at create
+  bool retreed = false;       // the 4-wide records are a collapse of retree_leaves' tree, not of the caller's inner nodes
   bool prunable = false;      // every leaf box holds its triangles (and the boxes are nested: the 4-wide records exist)
   double prune_G = 0.0;       // max 1 / sin(theta'/2) over the triangles with a bound (diagnostic)
   double prune_Z = 0.0;       // max distance of a vertex from its triangle's stored plane (diagnostic)
@@ -307,6 +311,155 @@ HostNode decode_node(const float* nodes, int i) {
     h.BB[k] = p[9 + k];
   }
   return h;
+}
+
+// ---- retree_leaves: OUR tree over the REFERENCE'S leaves (round 3).
+// For a tame ray and nested boxes the fp32 slab test is monotone (ezrt_traceq4.h), so the reference's hitBVH reaches a leaf
+// iff the slab test of the leaf's OWN box says hit: every ancestor's box contains it and is hit a fortiori.  The set of
+// leaves a ray visits -- and with it the set of triangles tested, the minimum of t, the exact ties -- therefore does not
+// depend on the inner nodes at all: ANY tree whose inner boxes are unions of the reference's leaf boxes visits exactly the
+// same leaves.  The reference's inner nodes are poor where its builder hits its `INF = 114514` cost cap (P3/main.cpp:492,
+// 538: the node silently becomes a median-x split; 180 nodes of the 10^6-triangle scene, all at the top), so the device
+// layout builds its own: a top-down binned SAH (32 bins per axis, cost = area x triangle count) over the reference's leaf
+// boxes, then the same 4-wide collapse.  The leaves -- boxes, triangle ranges, order -- are the reference's, untouched; the
+// binary records of the in-order kernel (redo launches, instrumented runs, counters P/I/T/M) stay the reference's tree.
+struct LeafPrim {
+  float c[3];
+  int node, w;
+};
+int retree_build(std::vector<LeafPrim>& pr, int begin, int end, const std::vector<HostNode>& ref, std::vector<HostNode>& out, int depth = 0) {
+  const int id = (int)out.size();
+  out.push_back(HostNode());
+  if (end - begin == 1) {
+    out[(size_t)id] = ref[(size_t)pr[(size_t)begin].node];
+    out[(size_t)id].left = out[(size_t)id].right = 0;
+    return id;
+  }
+  float clo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, chi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int i = begin; i < end; i++)
+    for (int a = 0; a < 3; a++) {
+      clo[a] = std::min(clo[a], pr[(size_t)i].c[a]);
+      chi[a] = std::max(chi[a], pr[(size_t)i].c[a]);
+    }
+  constexpr int NBMAX = 64;
+  // (16, 32 and 64 bins, and an exact sweep over sorted centroids for small or for all ranges, were within +-2 % of each
+  // other on C2 / C3 / C5: 32 bins)
+  static const int NB = [] { const char* e = getenv("EZRT_RETREE_BINS"); int v = e ? atoi(e) : 32; return v < 2 ? 2 : (v > NBMAX ? NBMAX : v); }();
+  double best = 1e300;
+  int best_axis = -1, best_split = -1;
+  for (int a = 0; a < 3; a++) {
+    const float ext = chi[a] - clo[a];
+    if (!(ext > 0.0f)) continue;
+    float lo[NBMAX][3], hi[NBMAX][3];
+    long long cnt[NBMAX];
+    for (int b = 0; b < NB; b++) {
+      cnt[b] = 0;
+      for (int k = 0; k < 3; k++) lo[b][k] = 3.0e38f, hi[b][k] = -3.0e38f;
+    }
+    const float scale = (float)NB / ext;
+    for (int i = begin; i < end; i++) {
+      int b = (int)((pr[(size_t)i].c[a] - clo[a]) * scale);
+      b = b < 0 ? 0 : (b > NB - 1 ? NB - 1 : b);
+      const HostNode& h = ref[(size_t)pr[(size_t)i].node];
+      cnt[b] += pr[(size_t)i].w;
+      for (int k = 0; k < 3; k++) {
+        lo[b][k] = std::min(lo[b][k], h.AA[k]);
+        hi[b][k] = std::max(hi[b][k], h.BB[k]);
+      }
+    }
+    // sweep: suffix boxes, then prefix
+    double ra[NBMAX];
+    long long rc[NBMAX];
+    float slo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, shi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    long long c = 0;
+    auto area = [](const float* l, const float* h) {
+      const double ex = (double)h[0] - l[0], ey = (double)h[1] - l[1], ez = (double)h[2] - l[2];
+      return (ex < 0 || ey < 0 || ez < 0) ? 0.0 : 2.0 * (ex * ey + ey * ez + ez * ex);
+    };
+    for (int b = NB - 1; b >= 1; b--) {
+      for (int k = 0; k < 3; k++) slo[k] = std::min(slo[k], lo[b][k]), shi[k] = std::max(shi[k], hi[b][k]);
+      c += cnt[b];
+      ra[b] = area(slo, shi);
+      rc[b] = c;
+    }
+    float plo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, phi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    long long lc = 0;
+    for (int b = 0; b < NB - 1; b++) { // split after bin b
+      for (int k = 0; k < 3; k++) plo[k] = std::min(plo[k], lo[b][k]), phi[k] = std::max(phi[k], hi[b][k]);
+      lc += cnt[b];
+      if (lc == 0 || rc[b + 1] == 0) continue;
+      const double cost = area(plo, phi) * (double)lc + ra[b + 1] * (double)rc[b + 1];
+      if (cost < best) {
+        best = cost;
+        best_axis = a;
+        best_split = b;
+      }
+    }
+  }
+  int mid;
+  if (best_axis >= 0 && depth < 40) { // (below 40 levels of SAH splits: medians, so that the depth stays bounded)
+    const float ext = chi[best_axis] - clo[best_axis], scale = (float)NB / ext, lo0 = clo[best_axis];
+    const int a = best_axis, sp = best_split;
+    auto it = std::partition(pr.begin() + begin, pr.begin() + end, [&](const LeafPrim& q) {
+      int b = (int)((q.c[a] - lo0) * scale);
+      b = b < 0 ? 0 : (b > NB - 1 ? NB - 1 : b);
+      return b <= sp;
+    });
+    mid = (int)(it - pr.begin());
+  } else {
+    mid = begin; // (all centroids equal, or no bin boundary separates them)
+  }
+  if (mid <= begin || mid >= end) { // object median along the widest centroid axis
+    int a = 0;
+    if (chi[1] - clo[1] > chi[a] - clo[a]) a = 1;
+    if (chi[2] - clo[2] > chi[a] - clo[a]) a = 2;
+    mid = (begin + end) / 2;
+    std::nth_element(pr.begin() + begin, pr.begin() + mid, pr.begin() + end,
+                     [a](const LeafPrim& x, const LeafPrim& y) { return x.c[a] < y.c[a] || (x.c[a] == y.c[a] && x.node < y.node); });
+  }
+  const int l = retree_build(pr, begin, mid, ref, out, depth + 1), r = retree_build(pr, mid, end, ref, out, depth + 1);
+  HostNode& h = out[(size_t)id];
+  h.left = l;
+  h.right = r;
+  h.n = 0;
+  h.index = 0;
+  for (int k = 0; k < 3; k++) { // exact unions: every box is nested in its parent's by construction
+    h.AA[k] = std::min(out[(size_t)l].AA[k], out[(size_t)r].AA[k]);
+    h.BB[k] = std::max(out[(size_t)l].BB[k], out[(size_t)r].BB[k]);
+  }
+  return id;
+}
+// tree[0] dummy, tree[1] root, children after parents; leaves are copies of the reference's reachable leaves
+bool retree_leaves(const std::vector<HostNode>& ref, int n_nodes, std::vector<HostNode>& tree) {
+  std::vector<LeafPrim> pr;
+  std::vector<int> todo(1, 1);
+  std::vector<char> seen((size_t)n_nodes, 0);
+  while (!todo.empty()) { // reachable leaves (the arrays are a tree here: checked by the caller)
+    const int i = todo.back();
+    todo.pop_back();
+    if (seen[(size_t)i]) continue;
+    seen[(size_t)i] = 1;
+    const HostNode& h = ref[(size_t)i];
+    if (h.n > 0) {
+      LeafPrim q;
+      for (int k = 0; k < 3; k++) q.c[k] = 0.5f * h.AA[k] + 0.5f * h.BB[k];
+      q.node = i;
+      q.w = h.n;
+      pr.push_back(q);
+    } else {
+      todo.push_back(h.right);
+      todo.push_back(h.left);
+    }
+  }
+  if (pr.size() < 2) return false;
+  for (const LeafPrim& q : pr)
+    for (int k = 0; k < 3; k++)
+      if (!(q.c[k] > -3.0e38f && q.c[k] < 3.0e38f)) return false; // (non-finite boxes: keep the reference's tree)
+  tree.clear();
+  tree.reserve(2 * pr.size() + 1);
+  tree.push_back(HostNode());
+  retree_build(pr, 0, (int)pr.size(), ref, tree);
+  return true;
 }
 
 int validate_params(const EzrtScene* s, const EzrtRenderParams* p) {
@@ -1229,7 +1382,9 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
   // ---- 4-wide collapse for traceq4_kernel (ezrt_traceq4.h).  Valid only when every box is nested in its
   // parent's box (true for the reference builders; checked here because the arrays are the caller's).
   std::vector<float4> inner4;
-  std::vector<std::array<int, 4>> rec_slot_nodes; // per record (in its final numbering): the caller's node of each slot, 0 = unused
+  std::vector<std::array<int, 4>> rec_slot_nodes; // per record (in its final numbering): tree4's node of each slot, 0 = unused
+  std::vector<HostNode> tree4;                    // the binary tree the records are a collapse of: the reference's, or retree_leaves'
+  bool retreed = false;
   int n_inner4 = 0, stack_need4 = 1;
   {
     std::vector<HostNode> hn((size_t)n_nodes);
@@ -1257,14 +1412,16 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
           if (!(hn[(size_t)k].AA[ax] >= c.AA[ax] && hn[(size_t)k].BB[ax] <= c.BB[ax])) nested = false; // (false on NaN)
     }
     if (nested) {
-      auto is_inner = [&](int i) { return inner_id[(size_t)i] >= 0; };
+      retreed = tuning_from_env().retree != 0 && retree_leaves(hn, n_nodes, tree4);
+      if (!retreed) tree4 = hn; // (node ids = the caller's)
+      auto is_inner = [&](int i) { return tree4[(size_t)i].n <= 0; };
       auto area = [&](int i) { // schedule heuristic only
-        const HostNode& h = hn[(size_t)i];
+        const HostNode& h = tree4[(size_t)i];
         float ex = h.BB[0] - h.AA[0], ey = h.BB[1] - h.AA[1], ez = h.BB[2] - h.AA[2];
         float a = ex * ey + ey * ez + ez * ex;
         return a == a ? a : 0.0f;
       };
-      auto leaf_pair = [&](int i) { return is_inner(i) && !is_inner(hn[(size_t)i].left) && !is_inner(hn[(size_t)i].right); };
+      auto leaf_pair = [&](int i) { return is_inner(i) && !is_inner(tree4[(size_t)i].left) && !is_inner(tree4[(size_t)i].right); };
       struct Rec {
         int node, m, slot[4];
       };
@@ -1272,7 +1429,7 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
       // splitting an inner slot (first a pair of leaves -- it would otherwise become a half-empty record of
       // its own -- else the one with the largest box) while there is room
       std::vector<Rec> recs;
-      std::vector<int> rec_of((size_t)n_nodes, -1);
+      std::vector<int> rec_of(tree4.size(), -1);
       std::vector<int> todo(1, 1);
       while (!todo.empty()) {
         const int x = todo.back();
@@ -1280,8 +1437,8 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
         Rec r;
         r.node = x;
         r.m = 2;
-        r.slot[0] = hn[(size_t)x].left;
-        r.slot[1] = hn[(size_t)x].right;
+        r.slot[0] = tree4[(size_t)x].left;
+        r.slot[1] = tree4[(size_t)x].right;
         while (r.m < 4) {
           int pick = -1;
           bool pick_pair = false;
@@ -1296,8 +1453,8 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
           }
           if (pick < 0) break;
           const int g = r.slot[pick];
-          r.slot[pick] = hn[(size_t)g].left;
-          r.slot[r.m++] = hn[(size_t)g].right;
+          r.slot[pick] = tree4[(size_t)g].left;
+          r.slot[r.m++] = tree4[(size_t)g].right;
         }
         rec_of[(size_t)x] = (int)recs.size();
         recs.push_back(r);
@@ -1345,7 +1502,7 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
           uint32_t rf = REF_EMPTY;
           for (int c = 0; c < 6; c++) v[c][k] = qnan; // unused slot: never hit (see ezrt_traceq4.h)
           if (k < r.m) {
-            const HostNode& g = hn[(size_t)r.slot[k]];
+            const HostNode& g = tree4[(size_t)r.slot[k]];
             for (int c = 0; c < 3; c++) {
               v[c][k] = g.AA[c];
               v[3 + c][k] = g.BB[c];
@@ -1486,9 +1643,9 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
       prune_A_med = 2.0 * fin[fin.size() / 2];
     }
     prune_a = __builtin_nextafterf((float)(2.0 * a_max), __builtin_inff());
-    std::vector<unsigned char> node_flag((size_t)n_nodes, 0); // (ids are topologically ordered: children after parents)
-    for (int i = n_nodes - 1; i >= 1; i--) {
-      const HostNode h = decode_node(nodes, i);
+    std::vector<unsigned char> node_flag(tree4.size(), 0); // (ids are topologically ordered: children after parents)
+    for (int i = (int)tree4.size() - 1; i >= 1; i--) {
+      const HostNode& h = tree4[(size_t)i];
       unsigned char f = 0;
       if (h.n > 0) {
         for (int k = h.index; k < h.index + h.n; k++) f |= eta[(size_t)k] > cutoff;
@@ -1588,6 +1745,7 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
   SC_TRY(hipMemcpy(s->inner.p, inner.data(), inner.size() * sizeof(float4), hipMemcpyHostToDevice));
   s->n_inner4 = n_inner4;
   s->stack_need4 = stack_need4;
+  s->retreed = retreed;
   s->prunable = prunable;
   s->prune_G = prune_G;
   s->prune_Z = prune_Z;
@@ -2117,7 +2275,7 @@ int ezrt_last_render_ms(EzrtScene* s, float* total_ms, float* trace_kernel_ms, i
   if (n_trace_launches) *n_trace_launches = s->n_trace_launches;
   return 0;
 }
-int ezrt_scene_prune_info(EzrtScene* s, double out[6]) {
+int ezrt_scene_prune_info(EzrtScene* s, double out[8]) {
   if (!s || !out) return fail(EZRT_ERR_INVALID, "NULL argument");
   out[0] = s->prunable ? (double)prune_mode(s) : -1.0;
   out[1] = s->prune_G;
@@ -2125,6 +2283,8 @@ int ezrt_scene_prune_info(EzrtScene* s, double out[6]) {
   out[3] = s->prune_M;
   out[4] = (double)s->prune_bad;
   out[5] = (double)s->prune_a;
+  out[6] = s->retreed ? 1.0 : 0.0;
+  out[7] = (double)s->n_inner4;
   return 0;
 }
 int ezrt_scene_stats(EzrtScene* s, int64_t out[6]) {

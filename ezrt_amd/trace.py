@@ -127,9 +127,9 @@ class Scene:
         return a.value, b.value, n.value
 
     def prune_info(self):
-        out = (C.c_double * 6)()
+        out = (C.c_double * 8)()
         self._ck(self._tl.lib.ezrt_scene_prune_info(self._h, out))
-        return dict(zip(("mode", "G", "Z", "M", "unprunable_triangles", "margin_a"), [float(x) for x in out]))
+        return dict(zip(("mode", "G", "Z", "M", "unprunable_triangles", "margin_a", "retreed", "records4"), [float(x) for x in out]))
 
     def stats(self):
         out = (C.c_int64 * 6)()

@@ -181,8 +181,10 @@ int ezrt_scene_stats(EzrtScene* s, int64_t out[6]);
  * nearest slot first; -1: not available for this scene -- a leaf box that does not hold its triangles, or boxes that are
  * not nested) [1] max 1/sin(theta'/2) over the triangles with a bound [2] max distance of a vertex from its triangle's
  * stored plane [3] max |coordinate| [4] triangles with a large bound or none (slivers: the records above them are never
- * pruned) [5] the launch's margin coefficient a.  The oracle (which never prunes) reports -1 and zeros. */
-int ezrt_scene_prune_info(EzrtScene* s, double out[6]);
+ * pruned) [5] the launch's margin coefficient a [6] 1 if the device's 4-wide records were built over the library's own SAH tree
+ * of the reference's LEAVES (EZRT_RETREE, default; the leaves, and so the results, are the reference's) [7] number of 4-wide
+ * records.  The oracle (which never prunes) reports -1 and zeros. */
+int ezrt_scene_prune_info(EzrtScene* s, double out[8]);
 
 /* Evaluate the deterministic math definitions on the implementation's compute
  * device (GPU for libezrt_hip) for the bit-equality test.  op: 0 sin, 1 cos,

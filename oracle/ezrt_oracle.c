@@ -1175,10 +1175,10 @@ int ezrt_last_render_ms(EzrtScene* s, float* total_ms, float* trace_kernel_ms, i
   if (n_trace_launches) *n_trace_launches = 1;
   return 0;
 }
-int ezrt_scene_prune_info(EzrtScene* s, double out[6]) { /* the oracle IS the unpruned traversal */
+int ezrt_scene_prune_info(EzrtScene* s, double out[8]) { /* the oracle IS the unpruned traversal */
   if (!s || !out) return fail(EZRT_ERR_INVALID, "NULL argument");
   out[0] = -1.0;
-  for (int k = 1; k < 6; k++) out[k] = 0.0;
+  for (int k = 1; k < 8; k++) out[k] = 0.0;
   return 0;
 }
 int ezrt_scene_stats(EzrtScene* s, int64_t out[6]) {
