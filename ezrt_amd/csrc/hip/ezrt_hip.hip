@@ -117,6 +117,7 @@ struct Tuning {
                            // record costs the stream ~5 us: -1.2 % on C2); 0: only the call's begin / end events
   int env_planes = 1;      // the env cache as an (x, y) plane and a pdf plane for bilinear lookups (one load per row)
   int env_rgbe = 1;        // environment lookups through the 4-byte RGBE form of the map when it has an exact one (set_env)
+  int min_staged = 16;      // a trace launch gives up workgroups per CU (down to 4) until this many top-of-tree records fit in LDS
   int rel_min_records = 24; // the primary stage runs at trace_wps_rel waves per SIMD only while that leaves this many top-of-tree records in LDS
   int gen_primary = 1;     // primary rays are generated inside the primary stage's trace and shading kernels (primary_dir) instead of
                            // written to a queue by raygen_kernel (timed pipeline with the 4-wide, eye-relative records only)
@@ -127,6 +128,8 @@ struct Tuning {
   int prune_mis = 2;       // ... of the MIS integrators' bounce stages (two rays per path, one an env shadow ray) when prune == 2:
                            // slot order there (1) was a wash on C4 (14.36 vs 14.28 Grays/s) and lost 6 % on C5 (2.46 vs 2.61)
   int prune_min_records = 0; // scenes with fewer 4-wide records than this are traced unpruned (small trees gain nothing)
+  int stack_cap = 0;       // prune 2: LDS stack rows of the nearest-first traversal before a ray is handed to the redo list (0: the exact
+                           // worst case of the slot-order traversal).  Fewer rows = more top-of-tree records staged in LDS
   int debug_stack_cap = 0; // test hook (prune 2): > 0 = stack rows beyond which a ray goes to the redo list, instead of the scene's bound
   int audit_via_queue = 0; // 1: ezrt_query_hits and ezrt_render_paths run through the TIMED kernels (traceq_kernel with
                            // the template, LDS layout, stealing and redo launch of a render call + the streaming shading
@@ -170,10 +173,12 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"debug_oom_above", &Tuning::debug_oom_above, 0, 1 << 30},
                               {"gen_primary", &Tuning::gen_primary, 0, 1},
                               {"rel_min_records", &Tuning::rel_min_records, 0, 4096},
+                              {"min_staged", &Tuning::min_staged, 0, 4096},
                               {"retree", &Tuning::retree, 0, 1},
                               {"prune", &Tuning::prune, 0, 2},
                               {"prune_mis", &Tuning::prune_mis, 0, 2},
                               {"prune_min_records", &Tuning::prune_min_records, 0, 1 << 24},
+                              {"stack_cap", &Tuning::stack_cap, 0, 64},
                               {"debug_stack_cap", &Tuning::debug_stack_cap, 0, 64},
                               {"audit_via_queue", &Tuning::audit_via_queue, 0, 2}};
 Tuning tuning_from_env() {
@@ -618,7 +623,11 @@ int prune_mode(const EzrtScene* s) {
 // stack rows of a traceq4 launch: the exact worst case of the slot-order traversal; the nearest-first order (prune 2)
 // has no small bound -- it runs with the same rows as its cap (a ray beyond it goes to the redo list) + three rows of
 // slack, because one step pushes up to three entries before the cap is tested
-int stack_rows4(const EzrtScene* s) { return s->stack_need4 + (prune_mode(s) == 2 ? 3 : 0); }
+int stack_cap4(const EzrtScene* s) { // (prune 2 only: the other modes have no overflow route)
+  const int c = s->tune.stack_cap;
+  return (c > 0 && c < s->stack_need4) ? c : s->stack_need4;
+}
+int stack_rows4(const EzrtScene* s) { return prune_mode(s) == 2 ? stack_cap4(s) + 3 : s->stack_need4; }
 int records_staged4(const EzrtScene* s, int wps) {
   const size_t lds_fixed = (size_t)stack_rows4(s) * BLOCK * sizeof(int) + BLOCK * sizeof(int);
   size_t budget = (size_t)(158 * 1024) / (size_t)(wps > 0 ? wps : 1);
@@ -629,7 +638,11 @@ int records_staged4(const EzrtScene* s, int wps) {
 int wps4(const EzrtScene* s, bool rel) {
   const int w = s->tune.trace_wps_rel;
   if (rel && w > 0 && (w <= s->tune.trace_wps || records_staged4(s, w) >= std::min(s->tune.rel_min_records, s->n_inner4))) return w;
-  return s->tune.trace_wps;
+  // deep trees (20 and more stack rows: C5, C3) leave a workgroup almost no LDS for the top of the tree at 6 per CU; one
+  // workgroup less per CU stages 50 records instead of 10 (C5 +5 %, C3 +1 %; C2 and C4, 16 rows, lose 5 % at 5 per CU)
+  int v = s->tune.trace_wps;
+  while (v > 4 && records_staged4(s, v) < std::min(s->tune.min_staged, s->n_inner4)) v--;
+  return v;
 }
 // rel: the launch traverses boxes translated by a common origin (traceq4_kernel<.., true>)
 TraceCfg trace_cfg4(const EzrtScene* s, bool rel) {
@@ -722,7 +735,7 @@ void fill_traceq4_args(const EzrtScene* s, const TraceCfg& c4, const TraceQArgs&
     const double eps = 1.0 / 16777216.0;
     A.prune_cs = __builtin_nextafterf((float)(2.0 * 17.0 * eps), __builtin_inff());
     A.prune_a = s->prune_a;
-    A.stack_cap = (s->tune.debug_stack_cap > 0 && s->tune.debug_stack_cap < s->stack_need4) ? s->tune.debug_stack_cap : s->stack_need4;
+    A.stack_cap = (s->tune.debug_stack_cap > 0 && s->tune.debug_stack_cap < stack_cap4(s)) ? s->tune.debug_stack_cap : stack_cap4(s);
   }
 }
 void launch_traceq4_cfg(EzrtScene* s, const TraceCfg& c4, const TraceQArgs& t, const float4* rel, hipStream_t st, const WfArgs* gen = nullptr) {
