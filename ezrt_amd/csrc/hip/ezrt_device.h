@@ -218,10 +218,26 @@ EZD float hit_aabb_tame(f3 S, f3 inv, f3 AA, f3 BB) {
   float t0 = hw_max3(hw_min(f.x, n.x), hw_min(f.y, n.y), hw_min(f.z, n.z));
   return (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
 }
+// hit_aabb_tame that also hands out the entry distance t0 = max_k of the near-plane products (for distance pruning)
+EZD float hit_aabb_tame_e(f3 S, f3 inv, f3 AA, f3 BB, float& t0_out) {
+  f3 f = (BB - S) * inv;
+  f3 n = (AA - S) * inv;
+  float t1 = hw_min3(hw_max(f.x, n.x), hw_max(f.y, n.y), hw_max(f.z, n.z));
+  float t0 = hw_max3(hw_min(f.x, n.x), hw_min(f.y, n.y), hw_min(f.z, n.z));
+  t0_out = t0;
+  return (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
+}
 EZD bool ray_is_tame(f3 S, f3 inv) {
   const float big = 3.0e38f;
   return ez_abs(S.x) < big && ez_abs(S.y) < big && ez_abs(S.z) < big && ez_abs(inv.x) < big && ez_abs(inv.y) < big &&
          ez_abs(inv.z) < big;
+}
+
+// a finite ray with at least one direction component exactly +-0 (1/d = +-inf there): see ezrt_traceq4.h
+EZD bool ray_is_semi(f3 S, f3 d, f3 inv) {
+  const float big = 3.0e38f;
+  const bool okx = ez_abs(inv.x) < big || d.x == 0.0f, oky = ez_abs(inv.y) < big || d.y == 0.0f, okz = ez_abs(inv.z) < big || d.z == 0.0f;
+  return ez_abs(S.x) < big && ez_abs(S.y) < big && ez_abs(S.z) < big && okx && oky && okz && (d.x == 0.0f || d.y == 0.0f || d.z == 0.0f);
 }
 
 // hitTriangle, distance part: P5/fsh:160-198.  Flipping N (fsh:175-178) negates

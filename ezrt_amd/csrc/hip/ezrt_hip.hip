@@ -121,6 +121,11 @@ struct Tuning {
   int rel_min_records = 24; // the primary stage runs at trace_wps_rel waves per SIMD only while that leaves this many top-of-tree records in LDS
   int gen_primary = 1;     // primary rays are generated inside the primary stage's trace and shading kernels (primary_dir) instead of
                            // written to a queue by raygen_kernel (timed pipeline with the 4-wide, eye-relative records only)
+  int semi = 1;            // rays with an exactly-zero direction component: 1 (default) traversed by the 4-wide kernel in the launches that
+                           // see them in numbers (the MIS integrators' bounce stages: SampleHdr's directions), 0 always the redo list
+                           // (in-order kernel, one lane per ray), 2 in every launch without a common origin
+  int tie_lca = 1;         // exact ties of the 4-wide kernel are ordered in place at the two leaves' lowest common ancestor in the
+                           // reference's tree (tie_precedes, ezrt_traceq4.h); 0: every tie goes to the redo list
   int retree = 1;          // READ AT SCENE CREATION (EZRT_RETREE): the 4-wide records are built over a binned-SAH tree of the
                            // reference's LEAVES instead of over a cut of the reference's own inner nodes (retree_leaves below)
   int prune = 2;           // traceq4_kernel's distance pruning (ezrt_traceq4.h "Distance pruning": proven results-neutral): 0 the
@@ -174,6 +179,8 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"gen_primary", &Tuning::gen_primary, 0, 1},
                               {"rel_min_records", &Tuning::rel_min_records, 0, 4096},
                               {"min_staged", &Tuning::min_staged, 0, 4096},
+                              {"semi", &Tuning::semi, 0, 2},
+                              {"tie_lca", &Tuning::tie_lca, 0, 1},
                               {"retree", &Tuning::retree, 0, 1},
                               {"prune", &Tuning::prune, 0, 2},
                               {"prune_mis", &Tuning::prune_mis, 0, 2},
@@ -230,6 +237,8 @@ struct EzrtScene {
   int n_materials = 0;
   DevBuf<float> tri_ref;
   DevBuf<float4> inner;
+  DevBuf<int32_t> tri_leaf;   // reference leaf node of every triangle; ref_up: per reference node (parent | depth << 24, parent's
+  DevBuf<int2> ref_up;        // binary record | is-right-child << 31) -- tie_precedes (empty: ties go to the redo list)
   DevBuf<float4> inner4;      // 4-wide records (ezrt_traceq4.h), breadth-first; empty when the boxes are not nested
   int n_inner4 = 0;
   int stack_need4 = 1;        // LDS stack rows the 4-wide traversal can need (exact worst case over hit patterns)
@@ -681,8 +690,15 @@ void launch_traceq4_v(EzrtScene* s, const TraceCfg& c, const TraceQ4Args& q, hip
   // (knob prune_mis: another order for the launches whose queue holds env shadow rays -- measured, not better)
   if (prune == 2 && q.q.rays_per_path == 2u && s->tune.prune_mis != 2) prune = s->tune.prune_mis;
   s->n_trace_launches++;
-  if (prune || GEN) { // (these variants exist for the two register budgets the launches use: 7 and 6 waves per SIMD)
-    if (trace_wps >= 7) {
+  // rays with an exactly-zero direction component stay in this kernel (SEMI) where they come in numbers: the env shadow
+  // rays of the MIS integrators' bounce stages (two rays per path); knob semi: 0 never, 2 every launch without a common origin
+  const bool semi = !REL && !GEN && (s->tune.semi == 2 || (s->tune.semi == 1 && q.q.rays_per_path == 2u));
+  if (prune || GEN || semi) { // (these variants exist for the two register budgets the launches use: 7 and 6 waves per SIMD)
+    if (semi) {
+      if (prune == 2) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 2, false, !REL>), grid, block, c.lds_t, st, q);
+      else if (prune == 1) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 1, false, !REL>), grid, block, c.lds_t, st, q);
+      else hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 0, false, !REL>), grid, block, c.lds_t, st, q);
+    } else if (trace_wps >= 7) {
       if (prune == 2) hipLaunchKernelGGL((traceq4_kernel<7, REL, LOG, 2, GEN>), grid, block, c.lds_t, st, q);
       else if (prune == 1) hipLaunchKernelGGL((traceq4_kernel<7, REL, LOG, 1, GEN>), grid, block, c.lds_t, st, q);
       else hipLaunchKernelGGL((traceq4_kernel<7, REL, LOG, 0, GEN>), grid, block, c.lds_t, st, q);
@@ -735,6 +751,8 @@ void fill_traceq4_args(const EzrtScene* s, const TraceCfg& c4, const TraceQArgs&
     const double eps = 1.0 / 16777216.0;
     A.prune_cs = __builtin_nextafterf((float)(2.0 * 17.0 * eps), __builtin_inff());
     A.prune_a = s->prune_a;
+    A.tri_leaf = (s->tune.tie_lca && s->tri_leaf.p && s->ref_up.p) ? s->tri_leaf.p : nullptr;
+    A.ref_up = s->ref_up.p;
     A.stack_cap = (s->tune.debug_stack_cap > 0 && s->tune.debug_stack_cap < stack_cap4(s)) ? s->tune.debug_stack_cap : stack_cap4(s);
   }
 }
@@ -756,6 +774,10 @@ void fill_trace_knobs(const EzrtScene* s, const TraceCfg& c, TraceQArgs& t) {
   t.pool_max = (uint32_t)(tu.pool_max < (int)TRACE_POOL_MIN ? (int)TRACE_POOL_MIN : (tu.pool_max > 4096 ? 4096 : tu.pool_max));
   t.stack_entries = (int32_t)(c.lds / (BLOCK * sizeof(int)));
   t.lds_nodes = c.lds_nodes;
+  // distance pruning of the binary kernel's in-order traversal (redo launches, wide4 = 0): same margin as traceq4_kernel's
+  t.prune_on = (s->prunable && tu.prune != 0 && s->instr == 0) ? 1u : 0u;
+  t.prune_a = s->prune_a;
+  t.prune_cs = __builtin_nextafterf((float)(2.0 * 17.0 / 16777216.0), __builtin_inff());
 }
 
 // ---- wavefront pipeline for one chunk of frames (all launches asynchronous on `st`)
@@ -1536,6 +1558,38 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
       }
     }
   }
+  // ---- tables of tie_precedes (ezrt_traceq4.h): only for arrays that are a tree with nested boxes (the 4-wide records exist)
+  // and whose leaves do not share triangles
+  std::vector<int32_t> tri_leaf_h;
+  std::vector<int2> ref_up_h;
+  if (n_inner4 > 0) {
+    tri_leaf_h.assign((size_t)n_tri, -1);
+    ref_up_h.assign((size_t)n_nodes, make_int2(0, 0));
+    bool ok = true;
+    for (int i = 1; i < n_nodes && ok; i++) {
+      if (depth[(size_t)i] == 0) continue; // unreachable
+      const HostNode h = decode_node(nodes, i);
+      if (h.n > 0) {
+        for (int k = h.index; k < h.index + h.n; k++) {
+          if (tri_leaf_h[(size_t)k] >= 0) ok = false; // a triangle in two leaves: no unique leaf
+          tri_leaf_h[(size_t)k] = i;
+        }
+      } else {
+        const int kids[2] = {h.left, h.right};
+        for (int c = 0; c < 2; c++)
+          ref_up_h[(size_t)kids[c]] = make_int2((int)((uint32_t)i | ((uint32_t)depth[(size_t)kids[c]] << 24)),
+                                               (int)((uint32_t)inner_id[(size_t)i] | (c ? 0x80000000u : 0u)));
+      }
+    }
+    ref_up_h[1] = make_int2((int)(1u << 24), 0);
+    if (!ok) {
+      tri_leaf_h.clear();
+      ref_up_h.clear();
+    } else {
+      for (int32_t& v : tri_leaf_h)
+        if (v < 0) v = 1; // (triangles no leaf holds are never tested)
+    }
+  }
   std::vector<float4> geom((size_t)n_tri * 3);
   for (int i = 0; i < n_tri; i++) {
     const float* t = tri + (size_t)i * EZRT_TRI_FLOATS;
@@ -1681,6 +1735,28 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
       memcpy(&inner4[q * N4_FLOAT4 + N4_ROW_REF], rf, sizeof rf);
     }
     root4_flag = node_flag[1] ? REF_NOPRUNE : 0u;
+    // the same flags per child in the BINARY records (the in-order kernel prunes too: ezrt_traceq.h), over the caller's tree
+    {
+      std::vector<unsigned char> rflag((size_t)n_nodes, 0);
+      for (int i = n_nodes - 1; i >= 1; i--) {
+        const HostNode h = decode_node(nodes, i);
+        unsigned char f = 0;
+        if (h.n > 0) {
+          for (int k = h.index; k < h.index + h.n; k++) f |= eta[(size_t)k] > cutoff;
+        } else {
+          f = rflag[(size_t)h.left] | rflag[(size_t)h.right];
+        }
+        rflag[(size_t)i] = f;
+      }
+      for (int i = 1; i < n_nodes; i++) {
+        if (inner_id[(size_t)i] < 0) continue;
+        const HostNode h = decode_node(nodes, i);
+        float4& q3 = inner[(size_t)inner_id[(size_t)i] * 4 + 3];
+        const uint32_t fl = rflag[(size_t)h.left] ? 1u : 0u, fr = rflag[(size_t)h.right] ? 1u : 0u;
+        memcpy(&q3.z, &fl, 4);
+        memcpy(&q3.w, &fr, 4);
+      }
+    }
     if (root4_flag) prune_flagged++;
   }
 
@@ -1768,6 +1844,12 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
   s->prune_bad = prune_bad;
   s->prune_flagged = prune_flagged;
   s->root4 = n_inner4 > 0 ? root4_flag : s->root_ref;
+  if (!tri_leaf_h.empty()) {
+    SC_TRY(s->tri_leaf.ensure(tri_leaf_h.size()));
+    SC_TRY(s->ref_up.ensure(ref_up_h.size()));
+    SC_TRY(hipMemcpy(s->tri_leaf.p, tri_leaf_h.data(), tri_leaf_h.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    SC_TRY(hipMemcpy(s->ref_up.p, ref_up_h.data(), ref_up_h.size() * sizeof(int2), hipMemcpyHostToDevice));
+  }
   if (n_inner4 > 0) {
     SC_TRY(s->inner4.ensure(inner4.size()));
     SC_TRY(hipMemcpy(s->inner4.p, inner4.data(), inner4.size() * sizeof(float4), hipMemcpyHostToDevice));

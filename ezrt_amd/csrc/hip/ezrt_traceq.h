@@ -81,6 +81,14 @@ struct TraceQArgs {
   uint32_t* redo_flag; // one word per ray slot: a ray is appended once (cleared again by the redo launch)
   uint32_t force_pending;       // test hook (knob debug_force_pending = k > 0): traceq4_kernel treats every ray whose slot is a
                                 // multiple of k as not tame, i.e. sends it through the pending -> redo -> second-pass route
+  // Distance pruning in THIS kernel's in-order traversal (prune_on != 0, never with FULLCTR: the counters are the unpruned
+  // reference's).  The margin and its proof are ezrt_traceq4.h's ("Distance pruning"); here the visit ORDER stays the
+  // reference's too -- a pruned child holds no triangle with t <= best_t, so neither the winner nor the first-found
+  // among exact ties changes -- which is what the redo launches (ties of the 4-wide kernel, rays that are not tame) need:
+  // without it a handful of tied rays walked the whole unpruned tree in ONE lane each (C5: 0.7 ms per stage, 11 % of a frame).
+  // A record's third word pair flags children with a triangle below them that has no useful bound.
+  uint32_t prune_on;
+  float prune_a, prune_cs;
   unsigned long long* wave_log; // diagnostic (debug_stages=2): per wave 8 words {start, end (100 MHz ticks), iterations |
                                 // inner steps, rays | inner lanes, leaf rays | leaf rounds, busy lanes, -, -}
 };
@@ -141,6 +149,13 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
   bool tie = false;    // two contributors published the same best distance for different triangles
   bool shared = false; // this lane's ray has been split: other lanes hold subtrees of it (or this lane is a thief)
   uint32_t ref = REF_NONE; // current node: inner record index (bit 31 clear), leaf ref (bit 31 set), or REF_NONE
+  const bool pruning = !FULLCTR && a.prune_on != 0u; // (wave-uniform)
+  float prune_t = INF, pdelta = 0.0f;                // skip a child whose entry distance exceeds (best_t + pdelta)(1 + 2^-19)
+  constexpr float PRUNE_REL_B = 1.0f + 1.0f / 524288.0f;
+  auto set_delta = [&]() {
+    pdelta = (a.prune_a + a.prune_cs * hw_max3(ez_abs(S.x), ez_abs(S.y), ez_abs(S.z))) * hw_max3(ez_abs(inv.x), ez_abs(inv.y), ez_abs(inv.z));
+    prune_t = (best_t + pdelta) * PRUNE_REL_B;
+  };
   Counters ctr = {0, 0, 0, 0, 0, 0, 0};
   uint32_t ray_p0 = 0, ray_t0 = 0, ray_i0 = 0, iters = 0;
   unsigned long long* hits64 = reinterpret_cast<unsigned long long*>(a.hits);
@@ -197,6 +212,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
           sp = 0;
           sb = 0;
           ref = sc.root_ref;
+          if (pruning) set_delta();
           ctr.rays += a.count_rays;
           if (FULLCTR) {
             ray_p0 = ctr.pops;
@@ -303,6 +319,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
             sp = 0;
             sb = 0;
             ref = (uint32_t)got;
+            if (pruning) set_delta();
             if (FULLCTR) {
               ray_p0 = ctr.pops;
               ray_t0 = ctr.tris;
@@ -353,6 +370,13 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
       } else if (wave_wild) { // some lane's ray has a zero/NaN direction component: exact select form
         d1 = hit_aabb(S, inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));
         d2 = hit_aabb(S, inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w));
+      } else if (pruning) { // (tame rays, absolute boxes: the redo launches)
+        float e1, e2;
+        d1 = hit_aabb_tame_e(S, inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), e1);
+        d2 = hit_aabb_tame_e(S, inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), e2);
+        // a child provably beyond the best hit is treated as missed (flagged children -- slivers below them -- never)
+        if (e1 > prune_t && __float_as_uint(q3.z) == 0u) d1 = -1.0f;
+        if (e2 > prune_t && __float_as_uint(q3.w) == 0u) d2 = -1.0f;
       } else {
         d1 = hit_aabb_tame(S, inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));
         d2 = hit_aabb_tame(S, inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w));
@@ -425,6 +449,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
             if (t < best_t) {
               best_t = t;
               best_tri = (int32_t)(uint32_t)mine;
+              if (pruning) prune_t = (t + pdelta) * PRUNE_REL_B;
             }
           }
         } else if (at_leaf) {
@@ -444,6 +469,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
             if (hit && t < best_t) {
               best_t = t;
               best_tri = i;
+              if (pruning) prune_t = (t + pdelta) * PRUNE_REL_B;
             }
           }
         }

@@ -19,8 +19,15 @@
 //    visit order only decides exact ties in t.  This kernel visits children in slot order (no near/far
 //    sorting at all), so EVERY exact tie at the running minimum -- in-lane or between contributors of a
 //    split ray -- sends the ray to the redo list, which the in-order binary kernel re-traces.
-//  * Rays that are not tame (a zero or non-finite direction component: NaNs can arise in the slab test and
-//    monotonicity is lost) go to the redo list unseen.
+//  * Rays with a direction component that is exactly +-0 ("semi": 1/d = +-inf there, everything else finite) are common in
+//    chapter 5 -- SampleHdr's phi is exactly 0 for every cache cell whose x is 0.5, so whole families of env shadow rays have
+//    L.z = 0 -- and each used to walk the tree in ONE lane of the in-order kernel (C5: 10 % of a frame in redo launches).
+//    Their slab products are finite or +-inf and ordered exactly like a tame ray's (the select form picks the near / far
+//    row by the sign of +-inf; an interval nested in another keeps its products inside the other's in the extended reals),
+//    EXCEPT 0 x inf = NaN when a box plane coincides with the origin on that axis, which hardware min3 / max3 would drop
+//    silently: waves holding such a ray test their products for NaN (used slots only: unused slots are NaN on purpose) and
+//    hand the ray to the redo list at the first one.  Their pruning margin is infinite (max |1/d| = inf): never pruned.
+//  * Rays that are not tame in any other way (non-finite origin or direction) go to the redo list unseen.
 //
 // Record (128 B in HBM = one L2 line, 112 B in LDS): AAx[4] AAy[4] AAz[4] BBx[4] BBy[4] BBz[4] ref[4] (pad);
 // an unused slot has an all-NaN box (v_min3/v_max3 of three NaNs is NaN and every compare with it is false:
@@ -65,6 +72,10 @@ struct TraceQ4Args {
   int32_t lds_nodes4;       // records [0, lds_nodes4) staged in LDS
   // PRUNE > 0 (see "Distance pruning" below): delta(ray) = (prune_a + prune_cs * |S|_inf) * max_k |1/d_k|
   float prune_a, prune_cs;
+  // exact ties resolved in place (see tie_precedes): the reference leaf of every triangle and, per reference node,
+  // x = parent | depth << 24, y = the parent's binary record | (1 << 31 if this node is the RIGHT child); NULL: ties go to the redo list
+  const int32_t* tri_leaf;
+  const int2* ref_up;
   // GEN (primary stage only): the queue holds no directions; the ray of queue position q is primary_dir(gen_*, q)
   EzrtRenderParams gen_p;
   const int2* gen_blocks;
@@ -170,13 +181,49 @@ EZD void chunk_prologue(const ChunkPrologue& g, uint32_t tid, uint32_t n_threads
 // longest path's, not one launch per bounce each as long as its deepest ray; exact ties and rays that are not tame are
 // then re-traced in the reference's order by the lane itself (hook.retrace), and there is no stealing (a split ray
 // would need a completion count before it can be shaded).
+// Which of two triangles with the SAME hit distance does the reference's hitBVH keep?  The first one it finds (strict <,
+// P5/fsh:247, 274), i.e. the one whose leaf comes first in its depth-first order: near child first at every node, ties
+// right-first (P5/fsh:291-298).  Two leaves are ordered at their lowest common ancestor alone -- the whole subtree of the
+// child visited first precedes the other's -- so the answer is two hitAABB calls on that node's children, found by climbing
+// from the two leaves (parent + depth per reference node), instead of re-tracing the ray in reference order: the redo
+// launches of C5 spent 0.2-1.5 ms per stage walking a few tied rays through the tree, one lane each (10 % of its frame).
+// Same leaf: the lower index (hitArray scans upwards).  Only called for rays that are tame.
+EZD bool tie_precedes(const TraceQ4Args& A, int32_t tri_a, int32_t tri_b, f3 S, f3 inv) {
+  int32_t a = A.tri_leaf[tri_a], b = A.tri_leaf[tri_b];
+  if (a == b) return tri_a < tri_b;
+  int2 ua = A.ref_up[a], ub = A.ref_up[b];
+  while (((uint32_t)ua.x >> 24) > ((uint32_t)ub.x >> 24)) {
+    a = ua.x & 0x00ffffff;
+    ua = A.ref_up[a];
+  }
+  while (((uint32_t)ub.x >> 24) > ((uint32_t)ua.x >> 24)) {
+    b = ub.x & 0x00ffffff;
+    ub = A.ref_up[b];
+  }
+  while ((ua.x & 0x00ffffff) != (ub.x & 0x00ffffff)) {
+    a = ua.x & 0x00ffffff;
+    b = ub.x & 0x00ffffff;
+    ua = A.ref_up[a];
+    ub = A.ref_up[b];
+  }
+  const float4* r = A.q.sc.inner + (size_t)((uint32_t)ua.y & 0x7fffffffu) * 4;
+  const float4 q0 = r[0], q1 = r[1], q2 = r[2];
+  const float d1 = hit_aabb(S, inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));
+  const float d2 = hit_aabb(S, inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w));
+  const bool left_first = d1 < d2; // (both children are hit: both leaves were reached)
+  return ((uint32_t)ua.y >> 31) ? !left_first : left_first;
+}
+
 struct NoPathHook {
   static constexpr bool PATH = false;
   EZD void retrace(f3, f3, int*, int32_t&, float&) const {}
   EZD bool shade(uint32_t, f3&, f3&, int32_t, float, int&) const { return false; }
   EZD int first_bounce() const { return 0; }
 };
-template <bool REL, bool LOG, int PRUNE, bool GEN, class Hook>
+// SEMI: rays with an exactly-zero direction component are traversed here (with the NaN watch) instead of sent to the redo
+// list.  A template parameter because the watch costs every ray of the launch 2-3 % (a ballot per iteration, four flags,
+// registers); the host turns it on for the launches that see such rays in numbers: the MIS integrators' bounce stages.
+template <bool REL, bool LOG, int PRUNE, bool GEN, class Hook, bool SEMI = false>
 EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
   static_assert(!GEN || REL, "generated rays start at the launch's uniform origin");
   extern __shared__ __attribute__((aligned(16))) int lds_stack[];
@@ -215,6 +262,8 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
   int sp = 0, sb = 0;
   bool tie = false;
   bool shared = false;
+  int32_t tie_tri = -1; // a second triangle at exactly best_t (ordered against best_tri when the ray is published)
+  bool semi = false;    // this lane's ray has a direction component that is exactly +-0 (see "Rays with a zero component")
   uint32_t ref = REF_NONE;
   uint32_t n_counted = 0;
   int bl = 0; // (Hook::PATH) the bounce this lane's path is in
@@ -239,6 +288,10 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
     sb = 0;
   };
   auto publish = [&]() {
+    if (tie_tri >= 0) { // two candidates at the final distance: the reference keeps the one it finds first
+      if (tie_precedes(A, tie_tri, best_tri, REL ? mk(a.origin[0], a.origin[1], a.origin[2]) : S, inv)) best_tri = tie_tri;
+      tie_tri = -1;
+    }
     if (shared) {
       if (best_tri >= 0) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(best_t) << 32) | (uint32_t)best_tri;
@@ -259,9 +312,11 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
     if (t < best_t) {
       best_t = t;
       best_tri = tri;
+      tie_tri = -1; // (a tie at a distance that has just been beaten does not matter any more)
       if (PRUNE) prune_t = (t + pdelta) * PRUNE_REL;
     } else if (t == best_t && tri != best_tri) {
-      tie = true;
+      if (A.tri_leaf && tie_tri < 0) tie_tri = tri; // ordered against best_tri at publish (tie_precedes)
+      else if (tri != tie_tri) tie = true;           // a third candidate (or no tables): the redo list
     }
   };
 
@@ -278,7 +333,9 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
       if (LOG && a.wave_log) dbg_refills++;
       if (Hook::PATH) {
         if (ref == REF_DONE) {
-          if (tie) hook.retrace(S, d, stack, best_tri, best_t); // exact tie / not tame: the reference's order, in this lane
+          if (tie_tri >= 0 && !tie && tie_precedes(A, tie_tri, best_tri, S, inv)) best_tri = tie_tri;
+          tie_tri = -1;
+          if (tie) hook.retrace(S, d, stack, best_tri, best_t); // a third tied candidate / not tame: the reference's order, in this lane
           tie = false;
           if (hook.shade(slot, S, d, best_tri, best_t, bl)) { // the path goes on: S, d = its next ray
             n_counted += a.count_rays;
@@ -287,7 +344,8 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
             best_tri = -1;
             sp = 0;
             sb = 0;
-            tie = !ray_is_tame(S, inv);
+            semi = SEMI && ray_is_semi(S, d, inv);
+            tie = !(ray_is_tame(S, inv) || semi);
             ref = tie ? REF_DONE : A.root4; // (a ray that is not tame is "finished" at once and re-traced at the next refill)
             if (PRUNE) set_delta();
           } else {
@@ -314,7 +372,9 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
           sb = 0;
           // a ray that is not tame (NaNs possible in the slab test, monotonicity lost) is not this kernel's: it is
           // "finished" at once with the tie flag set, i.e. published as PENDING and appended to the redo list
-          tie = !ray_is_tame(S, inv) || (a.force_pending && adopted % a.force_pending == 0u);
+          semi = SEMI && ray_is_semi(S, d, inv);
+          tie = !(ray_is_tame(S, inv) || semi) || (a.force_pending && adopted % a.force_pending == 0u);
+          tie_tri = -1;
           ref = tie ? REF_DONE : A.root4;
           best_tri = tie ? HIT_PENDING : -1;
           if (Hook::PATH) bl = hook.first_bounce();
@@ -400,7 +460,9 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
           const float vsx = REL ? a.origin[0] : __shfl(S.x, src, 64), vsy = REL ? a.origin[1] : __shfl(S.y, src, 64),
                       vsz = REL ? a.origin[2] : __shfl(S.z, src, 64);
           const float vdx = __shfl(d.x, src, 64), vdy = __shfl(d.y, src, 64), vdz = __shfl(d.z, src, 64);
+          const int vsemi = __shfl((int)semi, src, 64);
           if (thief) {
+            semi = vsemi != 0;
             shared = true;
             slot = vslot;
             S = mk(vsx, vsy, vsz);
@@ -461,7 +523,11 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
       }
       const float4 rf = make_float4(rfv.x, rfv.y, rfv.z, rfv.w);
       float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f, e3 = 0.0f; // PRUNE == 2: entry distances of the four slots
-      auto slab = [&](float nxk, float nyk, float nzk, float fxk, float fyk, float fzk, float& entry) -> bool {
+      // some lane of the wave holds a ray with a zero direction component: its slab products can be NaN (0 x inf), which
+      // the hardware min3 / max3 would silently drop -- such a lane leaves for the redo list the moment one turns up
+      const bool wave_semi = SEMI && ballot(semi && at_inner) != 0ull;
+      bool n0 = false, n1 = false, n2 = false, n3 = false; // a NaN among the slot's six products
+      auto slab = [&](float nxk, float nyk, float nzk, float fxk, float fyk, float fzk, float& entry, bool& nan_seen) -> bool {
         float t0x, t0y, t0z, t1x, t1y, t1z;
         if (REL) { // boxes already translated by the common origin
           t0x = nxk * inv.x, t0y = nyk * inv.y, t0z = nzk * inv.z;
@@ -472,16 +538,18 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
         }
         const float t1 = hw_min3(t1x, t1y, t1z);
         const float t0 = hw_max3(t0x, t0y, t0z);
+        if (wave_semi) nan_seen = ((t0x != t0x) | (t0y != t0y) | (t0z != t0z) | (t1x != t1x) | (t1y != t1y) | (t1z != t1z)) != 0;
         if (PRUNE == 2) entry = t0;
         // == hitAABB(..) > 0; PRUNE: ... and not provably beyond the best hit so far (see "Distance pruning")
         if (PRUNE) return (t1 >= t0) && (t1 > 0.0f) && !(t0 > thr);
         return (t1 >= t0) && (t1 > 0.0f);
       };
-      const bool h0 = slab(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, e0);
-      const bool h1 = slab(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, e1);
-      const bool h2 = slab(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, e2);
-      const bool h3 = slab(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, e3);
+      const bool h0 = slab(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, e0, n0);
+      const bool h1 = slab(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, e1, n1);
+      const bool h2 = slab(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, e2, n2);
+      const bool h3 = slab(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, e3, n3);
 #else
+      const bool wave_semi = false, n0 = false, n1 = false, n2 = false, n3 = false;
       static_assert(PRUNE == 0, "distance pruning is implemented on the EZRT_SLAB_SELECT form of the slab test");
       const float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f, e3 = 0.0f;
       float4 ax, ay, az, bx, by, bz, rf;
@@ -525,7 +593,12 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
 #endif
       const uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z),
                      r3 = __float_as_uint(rf.w);
-      if (PRUNE == 2) {
+      // (unused slots hold NaN boxes on purpose: only a NaN in a USED slot means 0 x inf)
+      const bool nan_slot = wave_semi && semi && ((n0 && r0 != REF_EMPTY) || (n1 && r1 != REF_EMPTY) || (n2 && r2 != REF_EMPTY) || (n3 && r3 != REF_EMPTY));
+      if (nan_slot) { // (rare) 0 x inf in a slab product: the NaN-aware in-order kernel decides this ray
+        tie = true;
+        finish();
+      } else if (PRUNE == 2) {
         // nearest first: continue with the hit slot of the smallest entry distance (so that the first leaves a ray
         // reaches are the likely winners and the rest gets pruned), push the other hit slots highest-first.  The order
         // is a heuristic only: pruning is exact whatever the order, exact ties still go to the redo list.
@@ -670,9 +743,9 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
   }
 }
 
-template <int WPS, bool REL, bool LOG = false, int PRUNE = 0, bool GEN = false>
+template <int WPS, bool REL, bool LOG = false, int PRUNE = 0, bool GEN = false, bool SEMI = false>
 __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
-  traceq4_body<REL, LOG, PRUNE, GEN>(A, NoPathHook());
+  traceq4_body<REL, LOG, PRUNE, GEN, NoPathHook, SEMI>(A, NoPathHook());
 }
 
 } // namespace ezd
