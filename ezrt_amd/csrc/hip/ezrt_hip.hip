@@ -66,7 +66,7 @@ struct Tuning {
   int megakernel = 0;      // 1: v1 one-lane-per-path kernel instead of the streaming pipeline
   int packet = 0;          // 1: packet traversal for primary rays (slower on C2: 1.48+0.61 ms vs 1.55 ms)
   int packet_budget = 48;  // steps after which a packet hands its rays to the per-lane kernel
-  int leaf_threshold = 24; // lanes waiting at a leaf that trigger the triangle phase
+  int leaf_threshold = 12; // lanes waiting at a leaf that trigger the triangle phase (24 until the traversal pruned: 12 is +3 % on C3 / C5 now)
   int pool_div = 1;        // ray-index pool = clamp(n_rays / (n_waves * pool_div), 8, pool_max)
   int pool_max = 128;      // rays per dynamic reservation (two 8x8 sub-blocks; affordable since the reservations spread over 8 counters)
   int trace_wps_rel = 7;   // waves per SIMD of the primary stage's launch (traceq4_kernel<.., true>; 0: trace_wps).  That variant
@@ -121,6 +121,8 @@ struct Tuning {
   int rel_min_records = 24; // the primary stage runs at trace_wps_rel waves per SIMD only while that leaves this many top-of-tree records in LDS
   int gen_primary = 1;     // primary rays are generated inside the primary stage's trace and shading kernels (primary_dir) instead of
                            // written to a queue by raygen_kernel (timed pipeline with the 4-wide, eye-relative records only)
+  int anyhit = 1;          // env shadow rays (the even slots of the MIS integrators' bounce stages) stop at their first accepted hit:
+                           // the shading stage only asks whether they hit anything (never in the audit routes)
   int semi = 1;            // rays with an exactly-zero direction component: 1 (default) traversed by the 4-wide kernel in the launches that
                            // see them in numbers (the MIS integrators' bounce stages: SampleHdr's directions), 0 always the redo list
                            // (in-order kernel, one lane per ray), 2 in every launch without a common origin
@@ -179,6 +181,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"gen_primary", &Tuning::gen_primary, 0, 1},
                               {"rel_min_records", &Tuning::rel_min_records, 0, 4096},
                               {"min_staged", &Tuning::min_staged, 0, 4096},
+                              {"anyhit", &Tuning::anyhit, 0, 1},
                               {"semi", &Tuning::semi, 0, 2},
                               {"tie_lca", &Tuning::tie_lca, 0, 1},
                               {"retree", &Tuning::retree, 0, 1},
@@ -775,6 +778,7 @@ void fill_trace_knobs(const EzrtScene* s, const TraceCfg& c, TraceQArgs& t) {
   t.stack_entries = (int32_t)(c.lds / (BLOCK * sizeof(int)));
   t.lds_nodes = c.lds_nodes;
   // distance pruning of the binary kernel's in-order traversal (redo launches, wide4 = 0): same margin as traceq4_kernel's
+  t.anyhit_even = 0u; // (set by the render pipeline for the MIS integrators' bounce stages)
   t.prune_on = (s->prunable && tu.prune != 0 && s->instr == 0) ? 1u : 0u;
   t.prune_a = s->prune_a;
   t.prune_cs = __builtin_nextafterf((float)(2.0 * 17.0 / 16777216.0), __builtin_inff());
@@ -1095,6 +1099,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     t.head = pp.qheads.p + (size_t)b * HEAD_SLOT;
     t.counters = s->counters.p;
     fill_trace_knobs(s, cfg, t);
+    t.anyhit_even = (mis && b > 0 && wide && !plog && !full && tu.anyhit) ? 1u : 0u;
     t.dbg = debug_stages ? (pp.qcounts.p + 100 + 4 * (b & 3)) : nullptr;
     t.slot_map = nullptr;
     t.steal = tu.steal ? 1u : 0u;

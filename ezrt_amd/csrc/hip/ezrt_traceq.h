@@ -89,6 +89,10 @@ struct TraceQArgs {
   // A record's third word pair flags children with a triangle below them that has no useful bound.
   uint32_t prune_on;
   float prune_a, prune_cs;
+  // 1 (traceq4_kernel, queues with two rays per path): the even slots are env shadow rays, of which the shading stage only
+  // asks WHETHER they hit anything (P5/fsh:826-829 `if(!hdrHit.isHit)`): their traversal stops at the first accepted hit.
+  // The record then holds A hit, not the closest one -- never set for the audit routes, which report {triangle, t}.
+  uint32_t anyhit_even;
   unsigned long long* wave_log; // diagnostic (debug_stages=2): per wave 8 words {start, end (100 MHz ticks), iterations |
                                 // inner steps, rays | inner lanes, leaf rays | leaf rounds, busy lanes, -, -}
 };

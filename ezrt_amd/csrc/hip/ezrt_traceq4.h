@@ -264,6 +264,7 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
   bool shared = false;
   int32_t tie_tri = -1; // a second triangle at exactly best_t (ordered against best_tri when the ray is published)
   bool semi = false;    // this lane's ray has a direction component that is exactly +-0 (see "Rays with a zero component")
+  bool anyhit = false;  // an env shadow ray: any accepted hit ends the traversal (TraceQArgs::anyhit_even)
   uint32_t ref = REF_NONE;
   uint32_t n_counted = 0;
   int bl = 0; // (Hook::PATH) the bounce this lane's path is in
@@ -373,6 +374,7 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
           // a ray that is not tame (NaNs possible in the slab test, monotonicity lost) is not this kernel's: it is
           // "finished" at once with the tie flag set, i.e. published as PENDING and appended to the redo list
           semi = SEMI && ray_is_semi(S, d, inv);
+          anyhit = a.anyhit_even != 0u && (adopted & 1u) == 0u;
           tie = !(ray_is_tame(S, inv) || semi) || (a.force_pending && adopted % a.force_pending == 0u);
           tie_tri = -1;
           ref = tie ? REF_DONE : A.root4;
@@ -460,9 +462,10 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
           const float vsx = REL ? a.origin[0] : __shfl(S.x, src, 64), vsy = REL ? a.origin[1] : __shfl(S.y, src, 64),
                       vsz = REL ? a.origin[2] : __shfl(S.z, src, 64);
           const float vdx = __shfl(d.x, src, 64), vdy = __shfl(d.y, src, 64), vdz = __shfl(d.z, src, 64);
-          const int vsemi = __shfl((int)semi, src, 64);
+          const int vsemi = __shfl((int)semi, src, 64), vany = __shfl((int)anyhit, src, 64);
           if (thief) {
             semi = vsemi != 0;
+            anyhit = vany != 0;
             shared = true;
             slot = vslot;
             S = mk(vsx, vsy, vsz);
@@ -717,11 +720,11 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
           }
         }
         if (at_leaf) {
-          if (sp > sb) {
+          if (sp > sb && !(anyhit && best_tri >= 0)) {
             sp--;
             ref = (uint32_t)stack[sp * BLOCK];
           } else {
-            finish();
+            finish(); // (an env shadow ray that has hit something is done: only isHit is asked of it)
           }
         }
       }

@@ -580,7 +580,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MISS_WAVES) void shade_miss_kern
 template <int INTEG, bool FULLCTR, int STAGE>
 // (The primary stage of the MIS integrators is compiled for 6 waves/SIMD, i.e. <= 80 VGPRs: with 8-wave workgroups the 83
 // registers it would take mean two workgroups per CU, 80 mean three -- C4 +2 %.  Their later stages want 116-122 and
-// would spill 50-100 registers; integrator 50 is faster left at 4.)
+// would spill 50-100 registers; integrator 50 (81 VGPRs, two workgroups per CU) measures the same at 6 and at 7 waves --
+// 76 and 72 registers, three workgroups: C2 and C3 within 0.3 % (round 3) -- and is left at 4.)
 __global__ __launch_bounds__(SHADE_BLOCK, (integ_mis<INTEG>() && STAGE == 0) ? 6 : 4) void shade_hit_kernel(WfArgs a) {
   __shared__ uint32_t alloc_lds[SHADE_BLOCK / 64 + 1];
   constexpr bool B0 = (STAGE == 0);

@@ -291,7 +291,9 @@ def test_schedule_knobs_never_change_results(hip, bunny_small):
                      {"path_stage": 0}, {"path_stage": 3}, {"path_stage": 2, "prune": 0}, {"path_stage": 2, "debug_force_pending": 3},
                      {"path_stage": 2, "debug_stack_cap": 1}, {"path_stage": 2, "lds_nodes": 0}, {"path_stage": 2, "refill_min": 1},
                      {"stack_cap": 4}, {"stack_cap": 9, "prune": 2}, {"min_staged": 0}, {"min_staged": 4096}, {"prune_mis": 1},
-                     {"semi": 0}, {"semi": 2}, {"semi": 2, "prune": 0}, {"tie_lca": 0}, {"tie_lca": 0, "semi": 0}):
+                     {"semi": 0}, {"semi": 2}, {"semi": 2, "prune": 0}, {"tie_lca": 0}, {"tie_lca": 0, "semi": 0},
+                     {"anyhit": 0}, {"anyhit": 0, "semi": 0}, {"anyhit": 1, "steal": 0}, {"anyhit": 1, "debug_force_pending": 3},
+                     {"anyhit": 1, "debug_stack_cap": 1}, {"anyhit": 1, "prune": 0}):
             s2 = bunny_small.upload(hip)
             for k, v in opts.items():
                 s2.set_option(k, v)

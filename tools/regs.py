@@ -8,7 +8,7 @@ cmd = "/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contr
       "-fno-slp-vectorize -Iinclude -Iezrt_amd/csrc/hip -c ezrt_amd/csrc/hip/ezrt_hip.hip -o /tmp/regs.o -Rpass-analysis=kernel-resource-usage"
 txt = subprocess.run(cmd.split(), cwd=ROOT, capture_output=True, text=True).stderr
 for b in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
-    name = b.split("\n")[0].strip()
+    name = b.split("\n")[0].split()[0].strip()
     dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
     if pat not in dem:
         continue
