@@ -82,6 +82,8 @@ struct Tuning {
   int static_pct = 50;     // share of a trace queue dealt statically to the waves, percent (0: one pool each)
   int refill_min = 24;     // free lanes a wave waits for before it runs its refill code (publish results, adopt the
                            // prefetched ray, prefetch the next): wave-wide code for per-lane events, so batch it (+9 %)
+  int refill_min_rel = 40; // ... of the primary stage's launch (rays with a common origin; 0: refill_min): its refill also generates the rays
+                           // (C2 +1.8 %, C4 +3.1 %, C3 / C5 +0.3 % over 24)
   int split_shade = 3;     // leaving paths and surface interactions shaded by two kernels: 1 from bounce 1 on, 2 always,
                            // 3 for the primary stage and bounce 1 only (the small late stages run the fused kernel: one
                            // launch less each, +0.6 %)
@@ -161,6 +163,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"rel_boxes", &Tuning::rel_boxes, 0, 1},
                               {"split_shade", &Tuning::split_shade, 0, 3},
                               {"refill_min", &Tuning::refill_min, 1, 64},
+                              {"refill_min_rel", &Tuning::refill_min_rel, 0, 64},
                               {"static_pct", &Tuning::static_pct, 0, 95},
                               {"pipes", &Tuning::pipes, 1, 2},
                               {"sub_frames", &Tuning::sub_frames, 0, 1 << 20},
@@ -746,6 +749,7 @@ void fill_traceq4_args(const EzrtScene* s, const TraceCfg& c4, const TraceQArgs&
   A.q.stack_entries = (int32_t)(c4.lds / (BLOCK * sizeof(int)));
   A.q.lds_nodes = 0;
   A.q.inner_rel = nullptr;
+  if (rel && s->tune.refill_min_rel > 0) A.q.refill_min = (uint32_t)s->tune.refill_min_rel;
   A.inner4 = s->inner4.p;
   A.inner4_rel = rel;
   A.root4 = s->root4;
