@@ -211,7 +211,7 @@ Tuning tuning_from_env() {
 
 // Scratch of one sub-chunk of frames in flight (see EzrtScene::pipe).
 struct Pipe {
-  DevBuf<float4> samples;
+  DevBuf<Sample3> samples;
   // wavefront queues (ping-pong)
   DevBuf<float4> rq_o[2], rq_d[2];
   DevBuf<float4> st[2][5];

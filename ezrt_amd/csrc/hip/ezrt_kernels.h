@@ -44,7 +44,7 @@ struct TraceArgs {
   const int2* blocks;   // origin (x, y) of each 16x16 pixel block to render
   int32_t n_blocks;
   uint32_t frame_first; // first frame of this launch
-  float4* samples;      // [n_frames][n_blocks * 256]
+  Sample3* samples;     // [n_frames][n_blocks * 256]
   unsigned long long* counters; // EZRT_CTR_COUNT
   int32_t* log_tri;     // PATHLOG: [H][W][slots]
   float* log_t;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
       a.log_colour[pix * 3 + 2] = colour.z;
     }
   }
-  if (!PATHLOG) a.samples[((size_t)fk * a.n_blocks + blk) * BLOCK + tid] = make_float4(colour.x, colour.y, colour.z, 1.0f);
+  if (!PATHLOG) a.samples[((size_t)fk * a.n_blocks + blk) * BLOCK + tid] = Sample3{colour.x, colour.y, colour.z};
 
   // counters: one atomic per wave per slot
   unsigned long long r = wave_sum(ctr.rays), s = wave_sum(samples);
@@ -309,7 +309,7 @@ struct AccumArgs {
   const int2* blocks;
   int32_t n_blocks;
   uint32_t frame_first, n_frames;
-  const float4* samples;
+  const Sample3* samples;
   float4* accum; // [H][W] RGBA
 };
 __global__ __launch_bounds__(BLOCK) void accumulate_kernel(AccumArgs a) {
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(AccumArgs a) {
   float4 last = a.accum[pix];
   f3 mean = mk(last.x, last.y, last.z);
   for (uint32_t k = 0; k < a.n_frames; k++) {
-    float4 c = a.samples[((size_t)k * a.n_blocks + blk) * BLOCK + tid];
+    const Sample3 c = a.samples[((size_t)k * a.n_blocks + blk) * BLOCK + tid];
     uint32_t frame = a.frame_first + k;
     if (frame == 0) {
       mean = mk(c.x, c.y, c.z);

@@ -54,7 +54,7 @@ struct WfArgs {
   int32_t n_blocks;
   uint32_t frame_first;
   uint32_t n_slots;        // n_blocks * 256 * n_frames
-  float4* samples;         // [n_slots]
+  Sample3* samples;        // [n_slots]
   unsigned long long* counters;
   RayQueue rq_in, rq_out;
   PathState st_in, st_out;
@@ -389,7 +389,7 @@ EZD bool shade_body(const WfArgs& a, const uint32_t i, bool live, const ShadeIn&
     colour = Le0 + Lo;
     done = true;
   }
-  if (live && done) a.samples[sslot] = make_float4(colour.x, colour.y, colour.z, 1.0f);
+  if (live && done) a.samples[sslot] = Sample3{colour.x, colour.y, colour.z};
 
   if (live && !done) {
     // ---- start bounce b (loop body of pathTracing*, P5/fsh:767-804 / 815-887)
@@ -458,7 +458,7 @@ EZD bool shade_body(const WfArgs& a, const uint32_t i, bool live, const ShadeIn&
     }
     if (!shoot && !(flags & FLAG_SHADOW_SHOT)) { // nothing pending: the path ends here
       f3 c2 = Le0 + Lo;
-      a.samples[sslot] = make_float4(c2.x, c2.y, c2.z, 1.0f);
+      a.samples[sslot] = Sample3{c2.x, c2.y, c2.z};
     } else {
       o.emit = true;
       if (!shoot) rayL = mk(0, 0, 0);
@@ -846,7 +846,7 @@ struct PathLogArgs {
   int32_t* log_tri;
   float* log_t;
   float* log_colour;     // pathcolour_kernel
-  const float4* samples;
+  const Sample3* samples;
 };
 __global__ __launch_bounds__(BLOCK) void pathlog_kernel(PathLogArgs a) {
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(BLOCK) void pathcolour_kernel(PathLogArgs a, EzrtRe
   uint32_t frame;
   slot_to_pixel(a.blocks, a.div_blocks, sslot, a.frame_first, x, y, frame);
   if (!pixel_owned(p, x, y)) return;
-  const float4 c = a.samples[sslot];
+  const Sample3 c = a.samples[sslot];
   const size_t pix = (size_t)y * a.width + x;
   a.log_colour[pix * 3 + 0] = c.x;
   a.log_colour[pix * 3 + 1] = c.y;
