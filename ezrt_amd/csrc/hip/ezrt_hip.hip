@@ -653,6 +653,9 @@ int records_staged4(const EzrtScene* s, int wps) {
 int wps4(const EzrtScene* s, bool rel) {
   const int w = s->tune.trace_wps_rel;
   if (rel && w > 0 && (w <= s->tune.trace_wps || records_staged4(s, w) >= std::min(s->tune.rel_min_records, s->n_inner4))) return w;
+  // (the primary stage's rays are coherent: the top of the tree is in the caches whether staged or not, and a workgroup more
+  // per CU is worth more than staged records -- C3 +2.8 % at 6 per CU with 6 records against 5 with 51)
+  if (rel && w > 0) return s->tune.trace_wps;
   // deep trees (20 and more stack rows: C5, C3) leave a workgroup almost no LDS for the top of the tree at 6 per CU; one
   // workgroup less per CU stages 50 records instead of 10 (C5 +5 %, C3 +1 %; C2 and C4, 16 rows, lose 5 % at 5 per CU)
   int v = s->tune.trace_wps;
