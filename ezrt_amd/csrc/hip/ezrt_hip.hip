@@ -82,6 +82,7 @@ struct Tuning {
   int static_pct = 50;     // share of a trace queue dealt statically to the waves, percent (0: one pool each)
   int refill_min = 24;     // free lanes a wave waits for before it runs its refill code (publish results, adopt the
                            // prefetched ray, prefetch the next): wave-wide code for per-lane events, so batch it (+9 %)
+  int lazy_dir = 1;        // the primary stage's first shading pass reads a ray's direction only after its hit record said "miss"
   int refill_min_rel = 40; // ... of the primary stage's launch (rays with a common origin; 0: refill_min): its refill also generates the rays
                            // (C2 +1.8 %, C4 +3.1 %, C3 / C5 +0.3 % over 24)
   int split_shade = 3;     // leaving paths and surface interactions shaded by two kernels: 1 from bounce 1 on, 2 always,
@@ -164,6 +165,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"split_shade", &Tuning::split_shade, 0, 3},
                               {"refill_min", &Tuning::refill_min, 1, 64},
                               {"refill_min_rel", &Tuning::refill_min_rel, 0, 64},
+                              {"lazy_dir", &Tuning::lazy_dir, 0, 1},
                               {"static_pct", &Tuning::static_pct, 0, 95},
                               {"pipes", &Tuning::pipes, 1, 2},
                               {"sub_frames", &Tuning::sub_frames, 0, 1 << 20},
@@ -991,6 +993,8 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
   }
   // primary rays generated where they are consumed (primary_dir) when stage 0 runs the 4-wide kernel on eye-relative records
   const bool gen_primary = wide && s->tune.rel_boxes && s->tune.gen_primary && !s->tune.packet;
+  a.all_owned = (p->shard_count <= 1 && p->x0 == 0 && p->y0 == 0 && p->x1 == p->width && p->y1 == p->height && p->width % 16 == 0 &&
+                 p->height % 16 == 0 && s->tune.lazy_dir) ? 1u : 0u;
   a.gen_primary = 0u; // (the shading passes read the directions the trace launch stored: see traceq4_kernel GEN)
   if (gen_primary) hipLaunchKernelGGL(chunk_prologue_kernel, dim3((unsigned)(4 * s->num_cus)), dim3(BLOCK), 0, st, a, pro);
   else hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((n_slots + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, a, pro);

@@ -293,7 +293,9 @@ def test_schedule_knobs_never_change_results(hip, bunny_small):
                      {"stack_cap": 4}, {"stack_cap": 9, "prune": 2}, {"min_staged": 0}, {"min_staged": 4096}, {"prune_mis": 1},
                      {"semi": 0}, {"semi": 2}, {"semi": 2, "prune": 0}, {"tie_lca": 0}, {"tie_lca": 0, "semi": 0},
                      {"anyhit": 0}, {"anyhit": 0, "semi": 0}, {"anyhit": 1, "steal": 0}, {"anyhit": 1, "debug_force_pending": 3},
-                     {"anyhit": 1, "debug_stack_cap": 1}, {"anyhit": 1, "prune": 0}):
+                     {"anyhit": 1, "debug_stack_cap": 1}, {"anyhit": 1, "prune": 0},
+                     {"lazy_dir": 0}, {"lazy_dir": 1, "debug_force_pending": 3}, {"refill_min_rel": 0}, {"refill_min_rel": 64},
+                     {"refill_min_rel": 1, "refill_min": 1}):
             s2 = bunny_small.upload(hip)
             for k, v in opts.items():
                 s2.set_option(k, v)
@@ -534,3 +536,19 @@ def test_pending_rays_take_the_redo_route_under_the_first_shading_pass(hip, orac
     sg.render(p)
     so.render(p)
     assert sg.counters()["rays"] == so.counters()["rays"] and sg.counters()["samples"] == so.counters()["samples"]
+
+
+def test_whole_block_frames_read_directions_lazily(hip, oracle, bunny_small):
+    """One shard and a frame of whole 16x16 blocks: the primary stage's first shading pass reads a ray's direction only after
+    its hit record said "miss" (knob lazy_dir).  Same frames with the knob off, against the oracle, for a plain and a MIS
+    integrator; a frame with a ragged edge (not whole blocks) takes the eager path by itself."""
+    so = bunny_small.upload(oracle)
+    eye, cam = S.camera(10, 5, 3)
+    for integ, mb in ((50, 3), (51, 2)):
+        for (w, h) in ((160, 128), (160, 120)):
+            p = trace.make_params(w, h, eye, cam, integ, mb, spp=2)
+            want = so.render(p)
+            for lazy in (1, 0):
+                sg = bunny_small.upload(hip)
+                sg.set_option("lazy_dir", lazy)
+                assert np.array_equal(_bits(sg.render(p)), _bits(want)), (integ, w, h, lazy)
