@@ -103,9 +103,11 @@ struct Tuning {
   int tail_stage = 0;      // from this stage on (>= 2; 0: never -- the default: measured 1.95 ms vs 0.43 ms for stages 2-4 of C2) the surviving paths finish in tail_kernel, one lane per
                            // path, instead of one trace + shading stage per bounce (ezrt_wavefront.h)
   int debug_stages = 0;    // print per-stage queue sizes (synchronises)
-  int redo_overlap = 1;    // the redo launch of a stage (exact ties, rays that are not tame: a handful of rays, but ~50 us of
-                           // dependent traversal steps) runs on a side stream under the stage's first shading pass; the
-                           // second pass waits for it (0: in line, before any shading)
+  int redo_overlap = 0;    // 1: the redo launch of a stage (exact ties beyond two candidates, rays that are not tame, stack overflows) runs on a
+                           // side stream under the stage's first shading pass and the second pass waits for it; 0 (default since round 3):
+                           // in line, before any shading.  The lists are EMPTY on the BASELINE configs since ties and zero-component rays
+                           // stay in the 4-wide kernel, an empty launch is ~4 us, and the two measure the same (C2 / C4 / C5 within 0.3 %)
+                           // -- without a cross-stream event wait in every frame (ezrt_streams.h: those can enter a slow state)
   int debug_oom_above = 0;     // test hook: chunk scratch for more than this many pixel-samples is reported as out of memory (exercises the
                                // smaller-chunk retry of ezrt_render_device)
   int debug_force_pending = 0; // test hook: every k-th ray slot takes the not-tame route (HIT_PENDING -> redo -> second pass)

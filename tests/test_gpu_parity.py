@@ -282,7 +282,7 @@ def test_schedule_knobs_never_change_results(hip, bunny_small):
                      {"refill_min": 1}, {"refill_min": 64}, {"split_shade": 0}, {"split_shade": 1}, {"split_shade": 2}, {"pipes": 2},
                      {"pipes": 2, "sub_frames": 1}, {"rel_boxes": 0}, {"wide4": 0}, {"wide4": 0, "steal": 0},
                      {"wide4": 0, "rel_boxes": 0}, {"tail_stage": 2}, {"tail_stage": 3, "wide4": 0}, {"refill_min": 16},
-                     {"redo_overlap": 0}, {"launch_events": 1}, {"chunk_log2": 12}, {"chunk_log2": 16}, {"shade_wgs": 1}, {"shade_wgs": 4096}, {"debug_oom_above": 30000}, {"debug_oom_above": 45000}, {"env_rgbe": 0}, {"env_planes": 0}, {"trace_wps_rel": 0}, {"trace_wps_rel": 5}, {"debug_force_pending": 3}, {"debug_force_pending": 1},
+                     {"redo_overlap": 0}, {"redo_overlap": 1}, {"redo_overlap": 1, "debug_force_pending": 2}, {"launch_events": 1}, {"chunk_log2": 12}, {"chunk_log2": 16}, {"shade_wgs": 1}, {"shade_wgs": 4096}, {"debug_oom_above": 30000}, {"debug_oom_above": 45000}, {"env_rgbe": 0}, {"env_planes": 0}, {"trace_wps_rel": 0}, {"trace_wps_rel": 5}, {"debug_force_pending": 3}, {"debug_force_pending": 1},
                      {"debug_force_pending": 5, "redo_overlap": 0}, {"debug_force_pending": 2, "split_shade": 2},
                      {"debug_force_pending": 7, "split_shade": 1}, {"debug_force_pending": 4, "split_shade": 0},
                      {"prune": 0}, {"prune": 1}, {"prune": 2}, {"prune": 1, "steal": 0}, {"prune": 2, "debug_stack_cap": 1},
@@ -523,6 +523,7 @@ def test_pending_rays_take_the_redo_route_under_the_first_shading_pass(hip, orac
     rays = so.counters()["rays"]
     for k in (1, 2, 3, 11):
         sg.set_option("debug_force_pending", k)
+        sg.set_option("redo_overlap", k & 1)  # (the side-stream route and the in-line one: the default since round 3)
         sg.counters_reset()
         assert np.array_equal(_bits(sg.render(p)), _bits(want)), (integ, k)
         sg.set_option("audit_via_queue", 1)
