@@ -15,10 +15,15 @@
 //    boxes of a "cut" of up to four descendants of one binary node (children, or grandchildren, ...), and a
 //    ray visits exactly the same leaves -- it tests fewer boxes and needs less than half the dependent
 //    memory round trips (C2: 0.43 record visits per binary inner visit).
-//  * The set of triangles tested is unchanged, the result is the minimum t over that set; the reference's
-//    visit order only decides exact ties in t.  This kernel visits children in slot order (no near/far
-//    sorting at all), so EVERY exact tie at the running minimum -- in-lane or between contributors of a
-//    split ray -- sends the ray to the redo list, which the in-order binary kernel re-traces.
+//  * The set of triangles tested is unchanged -- or, with distance pruning (below), reduced by triangles that provably
+//    cannot win or tie -- and the result is the minimum of t over that set; the reference's visit order only decides
+//    exact ties in t.  This kernel visits slots nearest-first (PRUNE == 2) or in slot order, never in the reference's
+//    order, so an exact tie at the running minimum is ordered explicitly: two candidates by two hitAABB calls at the lowest
+//    common ancestor of their leaves in the REFERENCE's tree (tie_precedes); a third candidate, a tie between the
+//    contributors of a split ray, or missing tables send the ray to the redo list, which the in-order binary kernel re-traces.
+//  * Since round 3 the records are usually NOT a collapse of the reference's inner nodes but of the library's own binned-SAH
+//    tree over the reference's LEAVES (retree_leaves, ezrt_hip.hip): by the first bullet a leaf is reached iff its own box
+//    is hit, whatever the inner boxes above it are, as long as they are unions of leaf boxes.
 //  * Rays with a direction component that is exactly +-0 ("semi": 1/d = +-inf there, everything else finite) are common in
 //    chapter 5 -- SampleHdr's phi is exactly 0 for every cache cell whose x is 0.5, so whole families of env shadow rays have
 //    L.z = 0 -- and each used to walk the tree in ONE lane of the in-order kernel (C5: 10 % of a frame in redo launches).
@@ -32,8 +37,9 @@
 // Record (128 B in HBM = one L2 line, 112 B in LDS): AAx[4] AAy[4] AAz[4] BBx[4] BBy[4] BBz[4] ref[4] (pad);
 // an unused slot has an all-NaN box (v_min3/v_max3 of three NaNs is NaN and every compare with it is false:
 // never hit, no extra instruction) and ref = REF_EMPTY.  Slots are ordered by ascending stack need of their
-// subtrees, visited lowest-first with the others pushed in descending order, which bounds the LDS stack by
-// max_j (pending_j + need_j) -- 16 rows on C2 where the binary traversal needs 18.
+// subtrees; without the nearest-first order (PRUNE < 2) they are visited lowest-first with the others pushed in descending
+// order, which bounds the LDS stack by max_j (pending_j + need_j) -- 16 rows on C2 where the binary traversal needs 18.  The
+// nearest-first order runs with that many rows + 3 and hands a ray that would need more to the redo list.
 //
 // Everything else (persistent waves, prefetched next ray, batched refill, static + dynamic pools, postponed
 // cooperative leaves, intra-wave stealing with the 64-bit atomicMin merge) is ezrt_traceq.h's schedule.
