@@ -32,9 +32,15 @@ $(LIBDIR)/libezrt_scene.so: $(HOST_SRC) include/ezrt_scene.hpp include/ezrt_scen
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(HOST_FLAGS) -shared -o $@ $(HOST_SRC)
 
-$(LIBDIR)/libezrt_hip.so: $(HIP_DEPS)
+# one object per translation unit (build/ is git-ignored; `make -j4 hip` compiles them in parallel, and a change to the
+# trace kernels does not recompile the rocPRIM-heavy builders)
+HIP_OBJ = $(patsubst ezrt_amd/csrc/hip/%.hip,build/hip/%.o,$(HIP_SRC))
+build/hip/%.o: ezrt_amd/csrc/hip/%.hip $(wildcard ezrt_amd/csrc/hip/*.h) $(wildcard include/*)
+	@mkdir -p build/hip
+	$(HIPCC) $(HIP_FLAGS) -c -o $@ $<
+$(LIBDIR)/libezrt_hip.so: $(HIP_OBJ)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIP_FLAGS) -shared -o $@ $(HIP_SRC) -ldl
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(HIP_OBJ) -ldl
 
 # Consumers of the public headers outside the libraries: chapter 5's main() ported onto the C ABI + the
 # C++ host API (g++ only: the boundary needs no HIP header), and a C11 layout check of the by-value struct.
@@ -50,7 +56,7 @@ $(EXDIR)/abi_layout_check: examples/abi_layout_check.c $(LIBDIR)/libezrt_scene.s
 	    -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)' -Wl,-rpath,$(ROCM)/lib -Wl,-rpath-link,$(ROCM)/lib
 
 clean:
-	rm -rf $(EXDIR)
+	rm -rf $(EXDIR) build/hip
 	rm -f $(LIBDIR)/*.so
 	$(MAKE) -C oracle clean
 

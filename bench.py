@@ -8,15 +8,25 @@ map = the reference's only shipped HDR (P4/HDR/peppermint_powerplant_4k.hdr, 102
 full render of that frame (64 spp) through libezrt_hip.so; scene, env map and the frame buffer are resident in HBM
 before the timed region.  ray := one hitBVH call, counted by the kernels.
 
+The N = 1 line also carries (round 4):
+  * `parity`: the frame the TIMED loop left (cloned right after the windows) compared on the bits with the frame of the
+    instrumented route (binary unpruned in-order kernel) and, in `cpu_baseline`, with the CPU oracle's complete frame;
+  * `configs`: BASELINE.json configs[2..4] (C3 / C4 / C5) timed at THEIR stated spp (128 / 256 / 512) -- one warm-up +
+    3 calls each -- with a crop of the timed frame checked on the bits against the oracle at the full spp;
+  * `scaling_model`: C2 and C4 rendered as shard r of N in {2, 4, 8} ALONE on this GPU (max over r = the critical
+    path of an N-GPU split) + pack + payload / 153 GB/s + un-permute = a predicted strong-scaling curve;
+  * `cpu_baseline.reference_shader_one_thread_Mrays_s`: the reference's own fshader.fsh (compiled by g++ into
+    oracle/_ref) timed on a crop of the same frames, next to the port's one-thread figure.
+
 N > 1 (one process per GPU, torchrun): the SAME workload, so that the per-N values of a scaling run are comparable:
 the C2 frame is cut into 16x16 tiles dealt round-robin to the ranks, the scene is replicated, every rank traces all
-spp of its tiles and ONE gather of the packed tiles to rank 0 over RCCL closes the frame.  Default "scaling": "weak"
-(spp x N: every GPU keeps the 1-GPU number of pixel-samples, the units are pixel-samples and they shard with no
-data-path collective before the closing gather); `--scaling strong` splits the fixed 64-spp frame N ways instead.
-Extra fields report per-rank render times, the gather time, the imbalance, the same frame rendered by rank 0 alone
-with a bitwise comparison (so the line carries its own 1-GPU reference), and BASELINE.json configs[3] (C4: P5 scene,
-integrator 51 = env importance sampling + MIS, 2 bounces, 1024x1024, 256 spp) as a FIXED frame split N ways
-(`c4_strong_variant`).  `--workload c2|c4` picks the main workload for any N.
+spp of its tiles and ONE gather of the packed tiles to rank 0 over RCCL closes the frame.  Default "scaling": "strong"
+(round 4: the metric reads "at fixed spp" -- the fixed 64-spp frame is split N ways; a weak run, spp x N, is
+near-linear by construction and is reported as the extra field `weak_variant`); `--scaling weak` makes the weak run
+the headline instead.  Extra fields report per-rank render times, the gather time, the imbalance, the same frame
+rendered by rank 0 alone with a bitwise comparison (so the line carries its own 1-GPU reference), and BASELINE.json
+configs[3] (C4: P5 scene, integrator 51 = env importance sampling + MIS, 2 bounces, 1024x1024, 256 spp) as a FIXED
+frame split N ways (`c4_strong_variant`).  `--workload c2|c4` picks the main workload for any N.
 
 Timing (VERDICT r2 / SURVEY 8(d) "median of >= 5 runs"): after W warm-up steps the script times `--windows` (default 7)
 windows of EXACTLY K steps, each bracketed by barrier + synchronize on both sides and reduced with MAX over ranks;
@@ -48,6 +58,10 @@ LDS_PEAK_GBS = 150000.0      # MI355X_MICROARCH.md "LDS": ~150 TB/s for ds_read_
 # add/mul/mov and the slab test's own opcode mix issue at 1.0-1.09 T wave-instructions/s chip-wide (~2 cycles per
 # instruction per SIMD at the ~2.1-2.4 GHz the chip sustains), fma/min3/cndmask alone at 0.58 T.
 VALU_ISSUE_PEAK_T = 1.086
+# ... and the guide's NOMINAL figure for the same ceiling: one wave64 fp32 VALU instruction per 2 cycles per SIMD x 4 SIMDs x
+# 256 CUs x 2.4 GHz (MI355X_MICROARCH.md "Chip-level parameters") = 1.229 T wave-instructions/s.  Both are printed.
+VALU_ISSUE_PEAK_NOMINAL_T = 256 * 4 * 2.4e9 / 2 / 1e12
+XGMI_LINK_GBS = 153.0        # MI355X_MICROARCH.md: one xGMI link, per direction (each peer's payload crosses its own link to rank 0)
 
 
 def alg_bytes(c, bilinear=True):
@@ -95,6 +109,7 @@ def physical_roofline(trace_ms_per_step, launches_per_step):
         "valu_wave_instr_per_step": int(insts),
         "issue_rate_T": round(insts / secs / 1e12, 4),
         "issue_frac": round(insts / secs / 1e12 / VALU_ISSUE_PEAK_T, 4),
+        "issue_frac_of_nominal_peak": round(insts / secs / 1e12 / VALU_ISSUE_PEAK_NOMINAL_T, 4),
         "lane_fill": round(k["SQ_THREAD_CYCLES_VALU"] / (64.0 * insts), 4),
         "salu_per_valu": round(k["SQ_INSTS_SALU"] / insts, 3),
         "wave_cycles_waiting": round(k["SQ_WAIT_ANY"] / k["SQ_WAVE_CYCLES"], 3),
@@ -111,6 +126,142 @@ def physical_roofline(trace_ms_per_step, launches_per_step):
     return out, None
 
 
+# crops of the timed full-spp frames that the CPU oracle re-renders (x0, y0, x1, y1), sized so that the oracle needs a few
+# seconds each at the full spp: C3 = the crop of tests/test_gpu_configs.py (1 863 distinct primary triangles over two spheres),
+# C4 / C5 = the 64x48 / 32x24 block of the frame with the most distinct primary triangles (691 on the Bunny / 745 on a sphere)
+CONFIG_CROPS = {"C3": (480, 380, 544, 428), "C4": (448, 288, 512, 336), "C5": (1024, 1128, 1056, 1152)}
+
+
+def load_oracle():
+    """The CPU oracle (test infrastructure): only the checker / cpu_baseline legs of this script call it."""
+    import ctypes
+    from ezrt_amd import _abi, trace
+    return trace.TraceLib(_abi.declare_trace_abi(ctypes.CDLL(os.path.join(ROOT, "oracle", "libezrt_oracle.so"))))
+
+
+def same_bits_nan_ok(a, b):
+    """bit equality, except that a NaN equals a NaN (include/ezrt.h: sign and payload of a NaN are not part of the contract)"""
+    import numpy as np
+    ua, ub = np.ascontiguousarray(a, np.float32).view(np.uint32), np.ascontiguousarray(b, np.float32).view(np.uint32)
+    return bool(((ua == ub) | (np.isnan(a) & np.isnan(b))).all())
+
+
+def build_config_scene(name, env):
+    from ezrt_amd import scenes
+    if name == "C3":
+        return scenes.disney_grid_scene(subdiv=3, hdr=env)
+    if name == "C4":
+        return scenes.p5_scene(subdiv=2, hdr=env)
+    if name == "C5":
+        return scenes.mega_scene(hdr=env)
+    raise ValueError(name)
+
+
+def time_config(name, hip, torch, dev, stream, env, spp_override=0, check=True, calls=3):
+    """One BASELINE config at its stated resolution / bounces / spp on this GPU: scene build + create timed separately, one
+    warm-up call + `calls` timed calls (each bracketed by synchronize; median), rays counted by the kernels, the trace
+    launches' share from one more call with launch events, and a crop of the frame the TIMED calls left compared on the
+    bits with the CPU oracle rendering that crop at the same spp."""
+    import numpy as np
+    from ezrt_amd import scene as S, scenes, trace
+    cfg = dict(scenes.CONFIGS[name])
+    if spp_override:
+        cfg["spp"] = spp_override
+    t0 = time.perf_counter()
+    bs = build_config_scene(name, env)
+    t_build = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    sc = bs.upload(hip)
+    torch.cuda.synchronize()
+    t_create = time.perf_counter() - t0
+    eye, cam = S.camera(*cfg["camera"])
+    W, H = cfg["width"], cfg["height"]
+    p = trace.make_params(W, H, eye, cam, cfg["integrator"], cfg["max_bounce"], spp=cfg["spp"], tile=(16, 16))
+    acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    t0 = time.perf_counter()
+    sc.render_device(p, acc.data_ptr(), stream)          # warm-up (allocates the chunk scratch)
+    torch.cuda.synchronize()
+    t_first = time.perf_counter() - t0
+    sc.counters_reset()
+    ms = []
+    for _ in range(calls):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sc.render_device(p, acc.data_ptr(), stream)
+        torch.cuda.synchronize()
+        ms.append((time.perf_counter() - t0) * 1e3)
+    rays = sc.counters()["rays"] // calls
+    frame = acc.clone()                                   # what the timed calls left
+    sc.set_option("launch_events", 1)
+    sc.render_device(p, acc.data_ptr(), stream)
+    torch.cuda.synchronize()
+    total_ms, trace_ms, n_launch = sc.last_render_ms()
+    sc.set_option("launch_events", 0)
+    med = statistics.median(ms)
+    out = {"workload": "%s: %d tris, %d BVH nodes, %dx%d, integrator %d, %d bounces, %d spp" %
+                       (name, bs.tri.shape[0], bs.nodes.shape[0], W, H, cfg["integrator"], cfg["max_bounce"], cfg["spp"]),
+           "Mrays_s": round(rays / (med * 1e-3) / 1e6, 2), "ms_per_frame": round(med, 3), "ms_per_frame_calls": [round(x, 3) for x in ms],
+           "rays": int(rays), "trace_ms": round(trace_ms, 3), "trace_launches": int(n_launch), "gpu_ms_with_launch_events": round(total_ms, 3),
+           "scene_build_s": round(t_build, 3), "scene_build": bs.build_stats if isinstance(bs.build_stats, dict) else None,
+           "scene_create_s": round(t_create, 3), "first_call_s": round(t_first, 3),
+           "non_finite_pixels": int((~torch.isfinite(frame[..., :3]).all(dim=2)).sum())}
+    if check:
+        x0, y0, x1, y1 = CONFIG_CROPS[name]
+        ora = load_oracle()
+        so = bs.upload(ora)
+        t0 = time.perf_counter()
+        want = so.render(trace.make_params(W, H, eye, cam, cfg["integrator"], cfg["max_bounce"], spp=cfg["spp"], rect=(x0, y0, x1, y1)))
+        got = frame[y0:y1, x0:x1].cpu().numpy()
+        out["crop_vs_oracle"] = {"rect": [x0, y0, x1, y1], "spp": cfg["spp"], "bit_identical": same_bits_nan_ok(got, want[y0:y1, x0:x1]),
+                                 "what": "the frame the timed calls left vs the CPU oracle on this crop at the same spp (NaN == NaN)",
+                                 "crop_max": float(np.nanmax(want[y0:y1, x0:x1, :3])), "oracle_s": round(time.perf_counter() - t0, 2)}
+        so.close()
+    sc.close()
+    return out
+
+
+def scaling_model(tag, sc, hip, torch, dev, stream, make_p, W, H, tile, shards=(2, 4, 8), reps=3):
+    """What an N-GPU strong split of this frame would cost, measured on ONE GPU: shard r of N rendered alone (the tiles rank r
+    would own; median of `reps` calls), max over r = the critical path of the render phase; + the pack kernel, the payload
+    over one xGMI link (each peer has its own link to rank 0), and the N - 1 un-permute kernels on rank 0.  RCCL's own
+    launch / protocol latency is NOT measurable here and is left out (stated in the field)."""
+    from ezrt_amd import tiles
+    acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return statistics.median(ts)
+
+    t1 = timed(lambda: sc.render_device(make_p((0, 1)), acc.data_ptr(), stream), reps)
+    out = {"workload": tag, "one_gpu_ms": round(t1, 4), "shards": {}}
+    for n in shards:
+        per = [timed(lambda r=r: sc.render_device(make_p((r, n)), acc.data_ptr(), stream), reps) for r in range(n)]
+        plan = tiles.TilePlan(W, H, tile, tile, n)
+        nfl = plan.per_rank * tile * tile * 4
+        packed = torch.zeros(nfl, dtype=torch.float32, device=dev)
+        a = (W, H, tile, tile)
+        pack = timed(lambda: hip.lib.ezrt_tiles_pack_device(acc.data_ptr(), *a, 1, n, packed.data_ptr(), stream), 5)
+        unpack = timed(lambda: hip.lib.ezrt_tiles_unpack_device(packed.data_ptr(), *a, 1, n, acc.data_ptr(), stream), 5)
+        wire = nfl * 4 / (XGMI_LINK_GBS * 1e9) * 1e3
+        crit = max(per)
+        total = crit + pack + wire + (n - 1) * unpack
+        out["shards"][str(n)] = {"render_ms_per_shard": [round(x, 4) for x in per], "critical_path_ms": round(crit, 4),
+                                 "imbalance_max_over_mean": round(crit / (sum(per) / n), 4),
+                                 "pack_ms": round(pack, 4), "wire_ms_at_153GBs": round(wire, 4), "unpack_ms_each": round(unpack, 4),
+                                 "payload_bytes_per_peer": nfl * 4, "predicted_ms": round(total, 4),
+                                 "predicted_speedup": round(t1 / total, 3), "render_only_speedup": round(t1 / crit, 3)}
+    out["note"] = ("pack / un-permute figures are host-synchronised single launches (they include ~10-20 us of launch + sync overhead each, "
+                   "i.e. pessimistic); RCCL's launch and protocol latency is not included (not measurable on one GPU)")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,9 +276,13 @@ def main():
     ap.add_argument("--subdiv", type=int, default=2)
     ap.add_argument("--tile", type=int, default=16)
     ap.add_argument("--env", choices=("shipped", "synthetic"), default="shipped")
-    ap.add_argument("--scaling", choices=("strong", "weak"), default="weak",
-                    help="N > 1 -- weak (default): spp x N, so every GPU keeps the 1-GPU number of pixel-samples; "
-                         "strong: the fixed frame is split N ways")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1 -- strong (default: the metric reads 'at fixed spp'): the fixed frame is split N ways; "
+                         "weak: spp x N, so every GPU keeps the 1-GPU number of pixel-samples")
+    ap.add_argument("--configs", default="C3,C4,C5",
+                    help="N = 1: BASELINE configs timed after the headline at their stated spp (comma list of C3,C4,C5; 'none' skips)")
+    ap.add_argument("--config-spp", type=int, default=0, help="override the spp of --configs (tests; 0 = BASELINE's 128 / 256 / 512)")
+    ap.add_argument("--model", type=int, default=1, help="N = 1: 0 skips the single-GPU scaling model")
     ap.add_argument("--windows", type=int, default=7, help="timed windows of --steps steps each; value = the median window")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time (0 = skip)")
     ap.add_argument("--extras", type=int, default=1, help="0: skip the extra fields (second camera, 1-GPU reference, weak variant)")
@@ -254,6 +409,10 @@ def main():
     gather_ev.clear()
     n_windows = max(1, args.windows)
     win_s, win_gpu_ms, win_host_ms, final = timed_windows(step, n_windows, args.steps)
+    # the frame the TIMED loop left, before anything else renders: every later pass (launch events, the instrumented route,
+    # the extras) writes into `scratch`, so `final` is what the parity fields below compare
+    final = final.clone()
+    scratch = torch.zeros_like(accum)
     gather_s = [a.elapsed_time(b) * 1e-3 for a, b in gather_ev]
     rays_timed = sc.counters()["rays"]          # over all windows (the workload is deterministic: the same rays every step)
     # per-step GPU times with a timing-event pair around every trace launch (hipEvents on the launch stream; reading them
@@ -262,7 +421,7 @@ def main():
     step_ms = []
     sc.set_option("launch_events", 1)
     for _ in range(7):
-        sc.render_device(p, accum.data_ptr(), stream)
+        sc.render_device(p, scratch.data_ptr(), stream)
         step_ms.append(sc.last_render_ms())
     sc.set_option("launch_events", 0)
 
@@ -347,6 +506,23 @@ def main():
                                             "linf_vs_n_gpu_frame": float(torch.nan_to_num(one - final, nan=0.0, posinf=0.0, neginf=0.0).abs().max()),
                                             "non_finite_pixels": int((~torch.isfinite(one[..., :3]).all(dim=2)).sum())}
             barrier()
+            if not weak:
+                # the weak variant (spp x N: every GPU keeps the 1-GPU number of pixel-samples) as an extra field: near-linear by
+                # construction -- each GPU repeats the 1-GPU work and only the closing gather is new -- so it is never `value` by default
+                pw = params((rank, world), n_spp=cfg["spp"] * world)
+                accw = torch.zeros_like(accum)
+                stepw = make_step(sc, pw, accw, plan)
+                stepw()
+                torch.cuda.synchronize()
+                sc.counters_reset()
+                ww, _, _, _ = timed_windows(stepw, 3, 2)
+                rw = torch.tensor([float(sc.counters()["rays"])], dtype=torch.float64, device=tdev)
+                dist.all_reduce(rw, op=dist.ReduceOp.SUM)
+                medw = sorted(ww)[1]
+                mg["weak_variant"] = {"workload": "the same scene and frame at %d spp (= %d spp x %d GPUs)" % (cfg["spp"] * world, cfg["spp"], world),
+                                      "scaling": "weak", "ms_per_step": round(medw / 2 * 1e3, 3), "window_ms": [round(x * 1e3, 3) for x in ww],
+                                      "Mrays_s": round(float(rw[0]) / 6 / (medw / 2) / 1e6, 2)}
+                barrier()
             # BASELINE.json configs[3] as a fixed frame split N ways (strong scaling): an extra field, never `value`
             c4 = dict(scenes.CONFIGS["C4"])
             if args.spp:
@@ -395,10 +571,17 @@ def main():
         # ---- roofline of the dominant kernel
         sc.set_instrumentation(1)
         sc.counters_reset()
-        sc.render_device(p, accum.data_ptr(), stream)
+        scratch.zero_()
+        sc.render_device(p, scratch.data_ptr(), stream)
         torch.cuda.synchronize()
         c = sc.counters()
         sc.set_instrumentation(0)
+        # two routes, one frame: the timed pipeline (4-wide pruning nearest-first traceq4_kernel, split shading, in-launch ray
+        # generation) and the instrumented one (binary UNPRUNED in-order traceq_kernel<true,6> = the reference's visit order)
+        out["parity"] = {"timed_frame_equals_instrumented_frame": bool(torch.equal(final.view(torch.int32), scratch.view(torch.int32))),
+                         "timed_frame": "cloned right after the timed windows (spp %d, frames 0..%d)" % (spp, spp - 1),
+                         "timed_frame_finite": bool(torch.isfinite(final).all()),
+                         "rays_timed_route_equals_instrumented_route": int(rays_per_step) == int(c["rays"])}
         # Dominant kernel = the persistent hitBVH over a ray queue (traceq4_kernel; 1 + max_bounce launches per step
         # + as many normally-empty redo launches of the in-order kernel).
         bytes_trace = 48 * c["node_pops"] + 96 * c["inner_pops"] + 72 * c["tri_tests"] + 72 * c["mat_fetch"]
@@ -415,9 +598,15 @@ def main():
             bound = max(fr, key=fr.get)
             rf.update({"bound": bound, "achieved": phys["issue_rate_T"] if bound == "valu_issue" else None,
                        "peak": VALU_ISSUE_PEAK_T, "unit": "T wave-instr/s", "frac": fr[bound],
+                       "peak_measured": VALU_ISSUE_PEAK_T, "peak_nominal": round(VALU_ISSUE_PEAK_NOMINAL_T, 4),
+                       "frac_of_nominal_peak": phys["issue_frac_of_nominal_peak"],
+                       "peak_note": "peak = this chip's measured wave64 fp32 issue rate for the slab test's opcode mix "
+                                    "(tools/exp_valu_issue.hip, profiles/r2/valu_issue_microbench.txt); peak_nominal = 256 CUs x 4 SIMDs x "
+                                    "2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)",
                        "traffic": phys["traffic_per_launch"], "ceilings": fr, "physical": phys})
         else:
             rf.update({"bound": "valu_issue", "achieved": None, "peak": VALU_ISSUE_PEAK_T, "unit": "T wave-instr/s", "frac": None,
+                       "peak_measured": VALU_ISSUE_PEAK_T, "peak_nominal": round(VALU_ISSUE_PEAK_NOMINAL_T, 4),
                        "traffic": None, "note_profile": why})
         rf["work_rate_vs_hbm"] = {
             "definition": "SURVEY.md 8(d): algorithmic bytes of the reference's unpruned traversal in the reference's record sizes "
@@ -463,11 +652,38 @@ def main():
                                                               "ms_per_step": round(dh / 5 * 1e3, 4),
                                                               "frame_bytes_each_way": int(H * W * 16)}
 
+        # ---- single-GPU scaling model: what an N-way strong split of C2 and of C4 would cost
+        c4_for_model = None
+        if args.model and args.extras and wl == "c2":
+            mdl = {"C2": scaling_model(out["config"]["workload"].split(",")[0] + ", %d spp" % spp, sc, hip, torch, dev, stream,
+                                       lambda sh: params(sh), W, H, args.tile)}
+            c4 = dict(scenes.CONFIGS["C4"])
+            if args.config_spp:
+                c4["spp"] = args.config_spp
+            bs4 = scenes.p5_scene(subdiv=args.subdiv, hdr=args.env)
+            sc4 = bs4.upload(hip)
+            e4, cam4 = S.camera(*c4["camera"])
+            mdl["C4"] = scaling_model("C4: P5 scene, integrator %d, %d bounces, %dx%d, %d spp" % (c4["integrator"], c4["max_bounce"], c4["width"],
+                                                                                            c4["height"], c4["spp"]), sc4, hip, torch, dev, stream,
+                                      lambda sh: trace.make_params(c4["width"], c4["height"], e4, cam4, c4["integrator"], c4["max_bounce"], spp=c4["spp"],
+                                                                   tile=(args.tile, args.tile), shard=sh), c4["width"], c4["height"], args.tile)
+            sc4.close()
+            mdl["predicted_speedup"] = {k: {n: v["shards"][n]["predicted_speedup"] for n in v["shards"]} for k, v in mdl.items() if "shards" in v}
+            out["scaling_model"] = mdl
+
+        # ---- BASELINE configs[2..4] at their stated spp (VERDICT r3 #1b), each with a crop of the timed frame checked against the oracle
+        names = [] if args.configs.strip().lower() in ("", "none") else [x.strip().upper() for x in args.configs.split(",")]
+        if names and wl == "c2":
+            out["configs"] = {}
+            for nm in names:
+                try:
+                    out["configs"][nm] = time_config(nm, hip, torch, dev, stream, args.env, args.config_spp, check=(args.cpu_seconds > 0))
+                except Exception as e:  # (one config failing must not cost the headline line; it is named in the line)
+                    out["configs"][nm] = {"error": "%s: %s" % (type(e).__name__, e)}
+
         # ---- CPU baseline: the oracle (a port, not the reference binary) on a bounded sample
         if args.cpu_seconds > 0:
-            from ezrt_amd import _abi
-            opath = os.path.join(ROOT, "oracle", "libezrt_oracle.so")
-            ora = trace.TraceLib(_abi.declare_trace_abi(ctypes.CDLL(opath)))
+            ora = load_oracle()
             so = bs.upload(ora)
             cores = host_cores()
             try:
@@ -514,6 +730,46 @@ def main():
                 gomp.omp_set_num_threads(cores)
             except OSError:
                 pass
+            # The reference's OWN trace on one host thread: part 5's shaders/fshader.fsh compiled by g++ into
+            # oracle/_ref/libezrt_ref_fsh_p5.so (oracle/ref_recipe/: a syntax-only source pass + a GLSL language shim; the file
+            # is built where /root/reference exists and travels with the snapshot).  Same scene, camera, integrator and frames on
+            # a centre crop; rays = the oracle's count for exactly that crop and those frames (same traversal definition).
+            try:
+                sys.path.insert(0, ROOT)
+                from oracle import ref as R
+                if R.fsh_available(5) and integ == 50:
+                    cw = min(64, W)
+                    rect = ((W - cw) // 2, (H - cw) // 2, (W - cw) // 2 + cw, (H - cw) // 2 + cw)
+                    f = R.Fsh(5)
+                    f.set_scene(bs.tri, bs.nodes)
+                    f.set_env(bs.hdr, bs.cache, 1 if bs.env_filter == 1 else 0)
+                    f.set_camera(eye, cam, W, H)
+                    f.set_integrator(mb, 0)
+                    nfr, dref = 0, 0.0
+                    ref_img = np.zeros((H, W, 4), np.float32)
+                    while dref < 3.0 and nfr < n_spp:       # ~3 s of the compiled shader, whole frames
+                        t1 = time.perf_counter()
+                        f.render(nfr, 1, ref_img, rect)
+                        dref += time.perf_counter() - t1
+                        nfr += 1
+                    gomp = ctypes.CDLL("libgomp.so.1")
+                    gomp.omp_set_num_threads(1)
+                    so.counters_reset()
+                    port_img = np.zeros((H, W, 4), np.float32)
+                    t1 = time.perf_counter()
+                    so.render(trace.make_params(W, H, eye, cam, integ, mb, spp=nfr, rect=rect), port_img)
+                    dport = time.perf_counter() - t1
+                    gomp.omp_set_num_threads(cores)
+                    rr = so.counters()["rays"]
+                    sl = (slice(rect[1], rect[3]), slice(rect[0], rect[2]))
+                    out["cpu_baseline"]["reference_shader_one_thread_Mrays_s"] = round(rr / dref / 1e6, 4)
+                    out["cpu_baseline"]["reference_shader"] = {
+                        "what": "the reference's part-5 fshader.fsh compiled for the host (oracle/_ref/libezrt_ref_fsh_p5.so), ONE thread",
+                        "sample": "crop %s, frames 0..%d (%d rays, %.2f s)" % (list(rect), nfr - 1, rr, dref),
+                        "port_one_thread_same_sample_Mrays_s": round(rr / dport / 1e6, 4),
+                        "port_frame_equals_reference_shader_frame": same_bits_nan_ok(port_img[sl], ref_img[sl])}
+            except (OSError, ImportError) as e:
+                out["cpu_baseline"]["reference_shader"] = {"skipped": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         if args.save_png:

@@ -106,6 +106,7 @@ BUILD_ABI = {
                                  c_float_p]),
     "ezrt_build_median": (C.c_int, [c_float_p, C.c_int, C.c_int, c_float_p, c_float_p, C.c_int, C.POINTER(C.c_int),
                                     c_float_p]),
+    "ezrt_build_device_count": (C.c_int, []),
 }
 
 

@@ -24,6 +24,11 @@ def build_lbvh(tri36, leaf_n=8):
     return _build("ezrt_build_lbvh", tri36, leaf_n)
 
 
+def device_count():
+    """HIP devices visible to this process (0 on a CPU-only box)."""
+    return int(_abi.load_hip().ezrt_build_device_count())
+
+
 def _build(entry, tri36, leaf_n):
     lib = _abi.load_hip()
     tri = np.ascontiguousarray(tri36, np.float32).reshape(-1, 36)

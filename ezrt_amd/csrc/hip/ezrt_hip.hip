@@ -647,6 +647,12 @@ int stack_cap4(const EzrtScene* s) { // (prune 2 only: the other modes have no o
   return (c > 0 && c < s->stack_need4) ? c : s->stack_need4;
 }
 int stack_rows4(const EzrtScene* s) { return prune_mode(s) == 2 ? stack_cap4(s) + 3 : s->stack_need4; }
+// stack rows of pathq4_kernel (knob path_stage): the nearest-first traversal's cap + 3 rows of slack whenever the launch prunes
+// (it instantiates PRUNE == 2 for every prune mode != 0), and the binary depth for the in-lane re-trace in reference order
+int path_rows(const EzrtScene* s) {
+  const int wide_rows = prune_mode(s) != 0 ? stack_cap4(s) + 3 : s->stack_need4;
+  return std::max(wide_rows, s->depth + 1);
+}
 int records_staged4(const EzrtScene* s, int wps) {
   const size_t lds_fixed = (size_t)stack_rows4(s) * BLOCK * sizeof(int) + BLOCK * sizeof(int);
   size_t budget = (size_t)(158 * 1024) / (size_t)(wps > 0 ? wps : 1);
@@ -1016,7 +1022,9 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
   if (shade_grid > shade_grid_max) shade_grid = shade_grid_max;
 
   const int tail_from = (!full && !plog && !debug_stages && tu.tail_stage >= 2) ? tu.tail_stage : (1 << 30);
-  const int path_from = (!full && !plog && !debug_stages && !mis && wide && tu.path_stage >= 2) ? tu.path_stage : (1 << 30);
+  // (a tree so deep that the fused launch's stack rows + lane table exceed the 64 KiB a launch gets without opt-in keeps the staged stages)
+  const bool path_fits = ((size_t)path_rows(s) + 1) * BLOCK * sizeof(int) <= 64 * 1024;
+  const int path_from = (!full && !plog && !debug_stages && !mis && wide && tu.path_stage >= 2 && path_fits) ? tu.path_stage : (1 << 30);
   for (int b = 0; b <= p->max_bounce; b++) {
     const int in = b & 1, out = in ^ 1;
     if (b >= path_from && b < tail_from) { // every later bounce of the chunk in one persistent launch (pathq4_kernel)
@@ -1027,7 +1035,9 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
       // LDS: stack rows for the nearest-first traversal AND for the in-lane reference-order re-trace (binary depth), the
       // lane table, then top-of-tree records; 4 workgroups per CU (the kernel is compiled for <= 128 VGPRs)
       TraceCfg c;
-      const int rows = std::max(stack_rows4(s), s->depth + 1);
+      // (the launch below always instantiates the nearest-first template when it prunes at all, whatever the knob says, and
+      // that order pushes up to three rows before its cap is tested: size for cap + 3 -- ADVICE r3)
+      const int rows = path_rows(s);
       c.lds = (size_t)rows * BLOCK * sizeof(int);
       const size_t lds_fixed = c.lds + BLOCK * sizeof(int);
       size_t budget = (size_t)(158 * 1024) / 4;
@@ -1035,9 +1045,9 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
       int nrec = budget > lds_fixed ? (int)((budget - lds_fixed) / (N4_LDS_DWORDS * 4)) : 0;
       nrec = std::min(nrec, std::min(s->n_inner4, tu.lds_nodes));
       c.lds_nodes = nrec < 0 ? 0 : nrec;
-      c.lds_t = lds_fixed + (size_t)c.lds_nodes * (N4_LDS_DWORDS * 4);
-      c.blocks_per_cu = 4;
-      c.grid_full = (unsigned)(s->num_cus * 4);
+      c.lds_t = lds_fixed + (size_t)c.lds_nodes * (N4_LDS_DWORDS * 4); // (<= 64 KiB: path_fits)
+      c.blocks_per_cu = lds_fixed > budget ? std::max(1, (int)((size_t)(158 * 1024) / lds_fixed)) : 4;
+      c.grid_full = (unsigned)(s->num_cus * c.blocks_per_cu);
       TraceQArgs t;
       t.sc = trace_scene(a.sc);
       t.rq = queue(in);
@@ -1452,8 +1462,8 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
       for (int i = 1; i < n_nodes && nested; i++) {
         if (inner_id[(size_t)i] < 0) continue;
         const int kids[2] = {hn[(size_t)i].left, hn[(size_t)i].right};
-        for (int k : kids)
-          if (inner_id[(size_t)k] >= 0 && ++n_parents[(size_t)k] > 1) nested = false;
+        for (int k : kids) // (leaves too: the tie tables hold ONE parent per node and the re-tree visits a leaf once -- ADVICE r3)
+          if (++n_parents[(size_t)k] > 1) nested = false;
       }
     }
     for (int i = 2; i < n_nodes && nested; i++) { // (the root's own box is never tested)
@@ -1464,8 +1474,10 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
         for (int ax = 0; ax < 3; ax++)
           if (!(hn[(size_t)k].AA[ax] >= c.AA[ax] && hn[(size_t)k].BB[ax] <= c.BB[ax])) nested = false; // (false on NaN)
     }
-    if (nested) {
-      retreed = tuning_from_env().retree != 0 && retree_leaves(hn, n_nodes, tree4);
+    // (two attempts at most: if the library's own tree over the leaves comes out so deep that the 4-wide kernel's stack rows
+    // would not fit its LDS -- use_wide4 -- the records are rebuilt as a cut of the CALLER's inner nodes, which may fit: ADVICE r3)
+    for (int attempt = 0; nested && attempt < 2; attempt++) {
+      retreed = attempt == 0 && tuning_from_env().retree != 0 && retree_leaves(hn, n_nodes, tree4);
       if (!retreed) tree4 = hn; // (node ids = the caller's)
       auto is_inner = [&](int i) { return tree4[(size_t)i].n <= 0; };
       auto area = [&](int i) { // schedule heuristic only
@@ -1574,6 +1586,7 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
         }
         o[N4_ROW_REF] = make_float4(v[6][0], v[6][1], v[6][2], v[6][3]);
       }
+      if (!retreed || ((size_t)stack_need4 + 4) * BLOCK * sizeof(int) <= 60 * 1024) break; // (the bound of use_wide4)
     }
   }
   // ---- tables of tie_precedes (ezrt_traceq4.h): only for arrays that are a tree with nested boxes (the 4-wide records exist)

@@ -505,3 +505,12 @@ extern "C" int ezrt_build_median(const float* tri, int n_tri, int leaf_n, float*
                                  int nodes_capacity, int* n_nodes, float* build_ms) {
   return build_level_sync(true, tri, n_tri, leaf_n, tri_out, nodes_out, nodes_capacity, n_nodes, build_ms);
 }
+
+extern "C" int ezrt_build_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError(); // (no device is an answer, not a sticky error)
+    return 0;
+  }
+  return n > 0 ? n : 0;
+}

@@ -8,7 +8,8 @@
   "integrator": 50,                      # 3 | 4 | 50 | 51 (ezrt.h)
   "camera": {"rotatAngle": 0, "upAngle": 0, "r": 4},
   "env": {"hdr": "sky.hdr", "filter": "bilinear", "clamp": 0},        # or {"synthetic": true}
-  "bvh": {"builder": "sah", "leaf": 8},                  # sah | sah_gpu (same tree, built on the GPU) | median | lbvh (GPU)
+  "bvh": {"builder": "sah", "leaf": 8},                  # sah (GPU builder from 100 000 triangles on, else host: same tree) |
+                                                         # sah_gpu | sah_host (force one) | median | lbvh (GPU, another tree)
   "objects": [
     {"obj": "bunny.obj", "smooth": true,
      "rotate": [0, 0, 0], "translate": [0.3, -1.6, 0], "scale": [1.5, 1.5, 1.5],
@@ -61,7 +62,7 @@ def build_scene(desc, base_dir="."):
         cache = S.calculateHdrCache(hdr) if (want_cache and hdr is not None) else None
         return scenes.BuiltScene("file", tri, nodes, {"lbvh_ms": ms}, hdr, cache, filt)
     return scenes._finish("file", hs, leaf, hdr, want_cache, filt, sah=(builder != "median"),
-                          gpu_build=(builder == "sah_gpu") or None)
+                          gpu_build=True if builder == "sah_gpu" else (False if builder == "sah_host" else None))
 
 
 def main(argv=None):

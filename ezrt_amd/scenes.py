@@ -153,13 +153,25 @@ class BuiltScene:
         return s
 
 
-# EZRT_GPU_BUILD=1: buildBVHwithSAH runs on the GPU (ezrt_build_sah: the same arrays, ~100x faster at 10^6 triangles)
-GPU_BUILD = os.environ.get("EZRT_GPU_BUILD", "0") not in ("", "0")
+# buildBVHwithSAH on the GPU (ezrt_build_sah: the SAME arrays as the host builder, bit for bit -- tests/test_gpu_lbvh.py --
+# ~70x faster at 10^6 triangles): the default for scenes of >= GPU_BUILD_MIN_TRIS triangles when a GPU is visible
+# (round 4); EZRT_GPU_BUILD=1 / 0 forces it on / off for every scene, gpu_build=True / False per call.
+GPU_BUILD_MIN_TRIS = 100_000
+
+
+def _auto_gpu_build(n_tri):
+    env = os.environ.get("EZRT_GPU_BUILD", "")
+    if env != "":
+        return env != "0"
+    if n_tri < GPU_BUILD_MIN_TRIS:
+        return False
+    from . import build
+    return build.device_count() > 0
 
 
 def _finish(name, hs, leaf_n, hdr, want_cache, env_filter, sah=True, gpu_build=None):
     if gpu_build is None:
-        gpu_build = GPU_BUILD
+        gpu_build = sah and _auto_gpu_build(hs.counts()[0])
     cache = S.calculateHdrCache(hdr) if (want_cache and hdr is not None) else None
     if sah and gpu_build:
         from . import build

@@ -35,6 +35,11 @@ int ezrt_build_sah(const float* tri, int n_tri, int leaf_n, float* tri_out, floa
 int ezrt_build_median(const float* tri, int n_tri, int leaf_n, float* tri_out, float* nodes_out, int nodes_capacity,
                       int* n_nodes, float* build_ms);
 
+/* Number of HIP devices this process can see (0 when there is none or the runtime cannot initialise): lets a host
+ * decide between ezrt_build_sah and the host buildBVHwithSAH -- both produce the same arrays -- without touching a
+ * device.  The Python layer picks the GPU builder for scenes of >= 100 000 triangles when this is > 0. */
+int ezrt_build_device_count(void);
+
 #ifdef __cplusplus
 }
 #endif

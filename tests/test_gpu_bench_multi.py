@@ -14,11 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(scaling, port):
+def _run(scaling, port, ranks=2, spp=8):
     env = dict(os.environ, EZRT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--windows", "3",
-           "--spp", "8", "--scaling", scaling, "--cpu-seconds", "0"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--windows", "3",
+           "--spp", str(spp), "--cpu-seconds", "0"] + (["--scaling", scaling] if scaling else [])
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -44,3 +44,51 @@ def test_bench_two_ranks_on_one_gpu(scaling, port):
     assert one["Mrays_s"] > 0
     c4 = mg["c4_strong_variant"]
     assert c4["Mrays_s"] > 0 and c4["one_gpu_same_frame"]["bit_identical_to_n_gpu_frame"] is True
+    if scaling == "strong":   # (round 4: the weak run is an extra field of the strong line)
+        w = mg["weak_variant"]
+        assert w["scaling"] == "weak" and w["Mrays_s"] > 0 and "16 spp" in w["workload"]
+    else:
+        assert "weak_variant" not in mg
+
+
+def test_bench_eight_ranks_on_one_gpu_default_is_strong():
+    """The driver's N = 8 command line (no --scaling flag) with all eight ranks on GPU 0 over gloo: the default is the STRONG
+    split of the fixed frame (VERDICT r3 #3), 128 tiles per rank, the frame bit-identical to the 1-GPU frame."""
+    out = _run(None, 29641, ranks=8, spp=4)
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong"
+    assert "4 spp" in out["config"]["workload"]
+    mg = out["multi_gpu"]
+    assert mg["tiles_per_rank"] == [128] * 8 and len(mg["render_ms_per_rank_median"]) == 8
+    assert mg["one_gpu_same_frame"]["bit_identical_to_n_gpu_frame"] is True
+    assert mg["c4_strong_variant"]["one_gpu_same_frame"]["bit_identical_to_n_gpu_frame"] is True
+    assert mg["weak_variant"]["Mrays_s"] > 0
+
+
+def test_bench_single_gpu_line_carries_parity_configs_and_model():
+    """The N = 1 line at reduced sizes (the driver's run uses the defaults): the timed frame equals the instrumented route's
+    frame and the CPU oracle's; C3 / C4 / C5 are timed with a crop of the timed frame equal to the oracle's; the scaling
+    model has C2 and C4 for 2 / 4 / 8 shards; both VALU peaks are printed; the reference's compiled shader is timed."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--windows", "3", "--spp", "3",
+           "--config-spp", "2", "--cpu-seconds", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["scaling"] == "n/a" and out["value"] > 0
+    par = out["parity"]
+    assert par["timed_frame_equals_instrumented_frame"] is True and par["rays_timed_route_equals_instrumented_route"] is True
+    assert out["cpu_baseline"]["linf_vs_gpu"] == 0.0 and out["cpu_baseline"]["kind"] == "port"
+    ref = out["cpu_baseline"]["reference_shader"]
+    assert ref["port_frame_equals_reference_shader_frame"] is True and out["cpu_baseline"]["reference_shader_one_thread_Mrays_s"] > 0
+    for nm in ("C3", "C4", "C5"):
+        c = out["configs"][nm]
+        assert "error" not in c, c
+        assert c["Mrays_s"] > 0 and c["rays"] > 0 and c["trace_ms"] > 0
+        assert c["crop_vs_oracle"]["bit_identical"] is True and c["crop_vs_oracle"]["crop_max"] > 0.05
+    rf = out["roofline"]
+    assert rf["peak_measured"] == 1.086 and abs(rf["peak_nominal"] - 1.2288) < 1e-3
+    for k in ("C2", "C4"):
+        sh = out["scaling_model"][k]["shards"]
+        assert set(sh) == {"2", "4", "8"} and all(v["predicted_speedup"] > 0 for v in sh.values())
+        assert len(sh["8"]["render_ms_per_shard"]) == 8

@@ -137,7 +137,9 @@ def test_c5_million_triangles_eight_bounces(hip, oracle, c5):
     """C5: exactly 10^6 triangles, 2048^2, integrator 51 with 8 bounces (Sobol dims wrap d & 7).
     Full resolution at reduced spp through the size-independent properties, oracle on a crop."""
     assert c5.tri.shape[0] == 1_000_000
-    assert c5.build_stats["inf_cap_nodes"] > 0          # the SAH INF=114514 cap is live at this size
+    # (scenes of this size are built by the GPU SAH builder by default since round 4 -- the same arrays as the host's,
+    # tests/test_gpu_lbvh.py; the host builder's statistics, incl. that the INF = 114514 cap is live here, are asserted there)
+    assert "gpu_build_ms" in c5.build_stats or c5.build_stats["inf_cap_nodes"] > 0
     cfg = scenes.CONFIGS["C5"]
     sg = c5.upload(hip)
     eye, cam = S.camera(*cfg["camera"])

@@ -203,6 +203,10 @@ def test_gpu_sah_builder_million_triangles(hip):
     print("C5 scene: host build path %.1f s, GPU build path %.1f s (device part %.0f ms)" %
           (t1 - t0, t2 - t1, b.build_stats["gpu_build_ms"]))
     assert np.array_equal(_bits(a.tri), _bits(b.tri)) and np.array_equal(_bits(a.nodes), _bits(b.nodes))
+    assert a.build_stats["inf_cap_nodes"] > 0          # the SAH INF = 114514 cap is live at this size (host builder's statistics)
+    # round 4: the GPU builder is the default from 100 000 triangles on when a GPU is visible (scenes._auto_gpu_build)
+    assert build.device_count() >= 1
+    assert scenes._auto_gpu_build(1_000_000) and not scenes._auto_gpu_build(99_999)
 
 
 @pytest.mark.parametrize("n,seed,ties,leaf", [(1, 1, False, 8), (300, 3, False, 8), (5000, 4, False, 4), (4000, 5, True, 8)])

@@ -19,7 +19,7 @@ def _frame_ms(sc, p, acc, st, torch, reps=9):
         sc.render_device(p, acc.data_ptr(), st)
         torch.cuda.synchronize()
         ms.append((time.perf_counter() - t0) * 1e3)
-    return min(ms)   # (the fastest of nine: what the kernels can do, whatever else the box was busy with)
+    return statistics.median(ms)   # (the median of nine: an intermittent slow state must show, a single noisy frame must not -- ADVICE r3)
 
 
 @pytest.mark.gpu
@@ -42,6 +42,9 @@ def test_scene_after_a_destroyed_scene_renders_the_same_bits_at_the_same_speed(h
             assert np.array_equal(f.view(np.uint32), frames[0].view(np.uint32))
         attempts.append(times)
         if max(times[1:]) < 1.12 * times[0] + 0.05:
+            if attempt:   # passed on a retry: say so, with every attempt's medians, instead of hiding it
+                import warnings
+                warnings.warn("scene lifecycle timing passed on attempt %d; medians per scene of every attempt: %r" % (attempt + 1, attempts))
             break
     else:
         raise AssertionError("later scenes render slower than the first in three attempts: %r" % (attempts,))
