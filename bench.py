@@ -738,8 +738,11 @@ def main():
                 sys.path.insert(0, ROOT)
                 from oracle import ref as R
                 if R.fsh_available(5) and integ == 50:
-                    cw = min(64, W)
-                    rect = ((W - cw) // 2, (H - cw) // 2, (W - cw) // 2 + cw, (H - cw) // 2 + cw)
+                    # (64x64 at 13/32, 11/32 of the frame: for C2's camera the Bunny's flank, floor and sky -- the crop of
+                    # tests/golden/make_fsh_golden.py's "c2_cam_r4"; the centre of that frame is sky only)
+                    cw = min(64, W, H)
+                    rx, ry = min((W * 13) // 32, W - cw), min((H * 11) // 32, H - cw)
+                    rect = (rx, ry, rx + cw, ry + cw)
                     f = R.Fsh(5)
                     f.set_scene(bs.tri, bs.nodes)
                     f.set_env(bs.hdr, bs.cache, 1 if bs.env_filter == 1 else 0)
@@ -747,7 +750,7 @@ def main():
                     f.set_integrator(mb, 0)
                     nfr, dref = 0, 0.0
                     ref_img = np.zeros((H, W, 4), np.float32)
-                    while dref < 3.0 and nfr < n_spp:       # ~3 s of the compiled shader, whole frames
+                    while dref < 3.0 and nfr < max(n_spp, 1024):   # ~3 s of the compiled shader, whole frames (any frame index is a valid sample)
                         t1 = time.perf_counter()
                         f.render(nfr, 1, ref_img, rect)
                         dref += time.perf_counter() - t1

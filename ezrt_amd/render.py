@@ -13,7 +13,8 @@
   "objects": [
     {"obj": "bunny.obj", "smooth": true,
      "rotate": [0, 0, 0], "translate": [0.3, -1.6, 0], "scale": [1.5, 1.5, 1.5],
-     "material": {"defaults": "p4", "baseColor": [1, 1, 1], "roughness": 0.5}}
+     "material": {"defaults": "p4", "baseColor": [1, 1, 1], "roughness": 0.5}},
+    {"triangles": [[[1, -1, 1], [-1, -1, -1], [-1, -1, 1]]], "material": {"baseColor": [1, 1, 1]}}   # inline triangles (part 1's Cornell box)
   ]
 }
 Paths are relative to the scene file.  Material keys are the fields of struct Material
@@ -38,11 +39,28 @@ def material_from(spec):
     return mk(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in spec.items()})
 
 
+def inline_triangles(tris, material):
+    """[[p1, p2, p3], ...] -> [n, 36] records in the reference's Triangle layout (P3/main.cpp:61-72): flat normal
+    normalize(cross(p2 - p1, p3 - p1)) in float32 at all three vertices, as part 1's Triangle constructor computes it."""
+    import numpy as np
+    out = []
+    m18 = material.to18()
+    for t in tris:
+        p1, p2, p3 = (np.array(p, np.float32) for p in t)
+        n = np.cross(p2 - p1, p3 - p1).astype(np.float32)
+        n = n / np.float32(np.sqrt(np.float32(n @ n)))
+        out.append(np.concatenate([p1, p2, p3, n, n, n, m18]).astype(np.float32))
+    return np.stack(out)
+
+
 def build_scene(desc, base_dir="."):
     """-> scenes.BuiltScene (host arrays in the reference layouts), following main()'s sequence:
     readObj per object, nodes = {testNode}, buildBVHwithSAH / buildBVH, encode."""
     hs = S.HostScene()
     for o in desc["objects"]:
+        if "triangles" in o:   # an inline triangle list (part 1's hard-coded Cornell box, P1/main.cpp:338-360): no OBJ, no normalisation
+            hs.addTriangles(inline_triangles(o["triangles"], material_from(o.get("material"))))
+            continue
         trans = S.getTransformMatrix(tuple(o.get("rotate", (0, 0, 0))), tuple(o.get("translate", (0, 0, 0))),
                                      tuple(o.get("scale", (1, 1, 1))))
         hs.readObj(os.path.join(base_dir, o["obj"]), material_from(o.get("material")), trans, bool(o.get("smooth", False)))
