@@ -2243,6 +2243,14 @@ int ezrt_query_hits(EzrtScene* s, const float* rays, int n_rays, int32_t* tri_id
     HIP_TRY(pp.qcounts.ensure(320));
     HIP_TRY(hipMemset(pp.qcounts.p, 0, 320 * sizeof(uint32_t)));
     const unsigned g1 = (unsigned)((n + 255) / 256);
+    // timing events as for a render call: ezrt_last_render_ms then reports this query (total = pack .. unpack, trace = the
+    // stage's trace + redo launches) -- how ray-order experiments time the TIMED kernel on caller-chosen rays
+    rc = ensure_events(s);
+    if (rc) return rc;
+    s->timed = false;
+    s->n_trace_events = 0;
+    s->n_trace_launches = 0;
+    HIP_TRY(hipEventRecord(s->ev_begin, nullptr));
     hipLaunchKernelGGL(query_pack_kernel, dim3(g1), dim3(256), 0, nullptr, dr.p, (uint32_t)n, pp.rq_o[0].p, pp.rq_d[0].p, pp.qcounts.p);
     const TraceCfg cfg = trace_cfg(s);
     const bool shared_origin = s->tune.audit_via_queue >= 2;
@@ -2283,6 +2291,7 @@ int ezrt_query_hits(EzrtScene* s, const float* rays, int n_rays, int32_t* tri_id
     t.redo_flag = pp.redo_flag.p;
     t.force_pending = 0u;
     t.wave_log = nullptr;
+    HIP_TRY(hipEventRecord(s->ev_trace[0][0], nullptr));
     if (wide) launch_traceq4_cfg(s, trace_cfg4(s, rel4 != nullptr), t, rel4, nullptr);
     else launch_traceq_cfg(s, cfg, t, false, nullptr);
     if (t.steal || wide) {
@@ -2294,7 +2303,11 @@ int ezrt_query_hits(EzrtScene* s, const float* rays, int n_rays, int32_t* tri_id
       r.head = pp.qheads.p + (size_t)40 * HEAD_SLOT;
       launch_traceq_cfg(s, cfg, r, true, nullptr);
     }
+    HIP_TRY(hipEventRecord(s->ev_trace[0][1], nullptr));
+    s->n_trace_events = 1;
     hipLaunchKernelGGL(query_unpack_kernel, dim3(g1), dim3(256), 0, nullptr, pp.hits2[0].p, (uint32_t)n, dtri.p, dt.p);
+    HIP_TRY(hipEventRecord(s->ev_end, nullptr));
+    s->timed = true;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(tri_id, dtri.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
