@@ -143,6 +143,9 @@ struct Tuning {
   int stack_cap = 0;       // prune 2: LDS stack rows of the nearest-first traversal before a ray is handed to the redo list (0: the exact
                            // worst case of the slot-order traversal).  Fewer rows = more top-of-tree records staged in LDS
   int debug_stack_cap = 0; // test hook (prune 2): > 0 = stack rows beyond which a ray goes to the redo list, instead of the scene's bound
+  int bounce_scatter = 1;  // the bounce stages' trace launches draw their queue in a scattered order, in granules of 8 rays
+                           // (TraceQ4Args::gscat_shift; 0: consecutive slots, the order the shading stage wrote; 1: queues with one
+                           // ray per path; 2: the MIS integrators' two-ray queues too -- measured slower there)
   int audit_via_queue = 0; // 1: ezrt_query_hits and ezrt_render_paths run through the TIMED kernels (traceq_kernel with
                            // the template, LDS layout, stealing and redo launch of a render call + the streaming shading
                            // stages) instead of the in-order audit kernels; 2 (query only): additionally treat the rays as
@@ -197,6 +200,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"prune_min_records", &Tuning::prune_min_records, 0, 1 << 24},
                               {"stack_cap", &Tuning::stack_cap, 0, 64},
                               {"debug_stack_cap", &Tuning::debug_stack_cap, 0, 64},
+                              {"bounce_scatter", &Tuning::bounce_scatter, 0, 2},
                               {"audit_via_queue", &Tuning::audit_via_queue, 0, 2}};
 Tuning tuning_from_env() {
   Tuning t;
@@ -713,6 +717,12 @@ void launch_traceq4_v(EzrtScene* s, const TraceCfg& c, const TraceQ4Args& q, hip
   // rays of the MIS integrators' bounce stages (two rays per path); knob semi: 0 never, 2 every launch without a common origin
   const bool semi = !REL && !GEN && (s->tune.semi == 2 || (s->tune.semi == 1 && q.q.rays_per_path == 2u));
   if (prune || GEN || semi) { // (these variants exist for the two register budgets the launches use: 7 and 6 waves per SIMD)
+    // (the scattered draw exists for the default schedule of the bounce stages: pruning with the nearest-first order, no log)
+    if (!REL && !GEN && !LOG && prune == 2 && q.gscat_shift != 0u && trace_wps < 7) {
+      if (semi) hipLaunchKernelGGL((traceq4_kernel<6, false, false, 2, false, true, true>), grid, block, c.lds_t, st, q);
+      else hipLaunchKernelGGL((traceq4_kernel<6, false, false, 2, false, false, true>), grid, block, c.lds_t, st, q);
+      return;
+    }
     if (semi) {
       if (prune == 2) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 2, false, !REL>), grid, block, c.lds_t, st, q);
       else if (prune == 1) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 1, false, !REL>), grid, block, c.lds_t, st, q);
@@ -775,6 +785,11 @@ void fill_traceq4_args(const EzrtScene* s, const TraceCfg& c4, const TraceQArgs&
     A.ref_up = s->ref_up.p;
     A.stack_cap = (s->tune.debug_stack_cap > 0 && s->tune.debug_stack_cap < stack_cap4(s)) ? s->tune.debug_stack_cap : stack_cap4(s);
   }
+  // (the even / odd slots of a two-ray path must stay in one granule: any granule >= 2 slots does)
+  // knob bounce_scatter: 1 (default) = queues with one ray per path only.  Measured in the pipeline (profiles/r4/bounce_scatter_ab.txt):
+  // C2 +2.7 % (trace launches 1.39 -> 1.345 ms), C3 -0.5 % (noise); the MIS integrators' queues (two rays per path sharing an
+  // origin, env shadow rays that are coherent by construction) LOSE 1.3 % (C4) and 2.8 % (C5) with it: 2 = those too
+  A.gscat_shift = (!rel && !gen && !t.slot_map && (s->tune.bounce_scatter == 2 || (s->tune.bounce_scatter == 1 && t.rays_per_path == 1u))) ? 3u : 0u;
 }
 void launch_traceq4_cfg(EzrtScene* s, const TraceCfg& c4, const TraceQArgs& t, const float4* rel, hipStream_t st, const WfArgs* gen = nullptr) {
   TraceQ4Args A;

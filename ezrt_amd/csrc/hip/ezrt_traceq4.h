@@ -89,6 +89,16 @@ struct TraceQ4Args {
   uint32_t gen_scatter, gen_scatter_shift, gen_frame_first;
   int32_t stack_cap;        // PRUNE == 2: live stack rows beyond which a ray is handed to the redo list (the launch
                             // allocates stack_cap + 3 rows: one step pushes at most three)
+  // Queue positions are DRAWN in a scattered order (bounce stages; 0 = off, else the template parameter GS): granules of 8 consecutive slots,
+  // logical granule g -> physical granule (g mod 256) * R + g / 256, R = ceil(granules / 256) -- a transpose, so that the 16
+  // granules of a wave's pool come from 16 places spread over a sixteenth of the queue instead of from one run of 128 slots.
+  // A shading workgroup writes its survivors as a run (a few hundred rays from a handful of 8x8 pixel blocks), so
+  // consecutive slots cost about the same and a wave that drew an expensive run was the launch's tail: measured on
+  // synthetic bounce rays (tools/exp_ray_order.py, profiles/r4/ray_order_experiment_*.txt) granules of 8 shuffled are as
+  // fast as a fully random order, C2 -15 % trace time, C3 -3.5 %, C5 +-0 -- and SORTING the rays for coherence (origin
+  // cell, direction octant, Morton) is 5-20 % SLOWER than the pipeline's order: mixing cheap and expensive rays in every
+  // wave is worth more than coherent memory accesses.  Only the order of processing changes: every ray keeps its slot.
+  uint32_t gscat_shift;
 };
 
 // ---- Distance pruning (PRUNE > 0): results-neutral, proven, not merely observed.
@@ -229,7 +239,7 @@ struct NoPathHook {
 // SEMI: rays with an exactly-zero direction component are traversed here (with the NaN watch) instead of sent to the redo
 // list.  A template parameter because the watch costs every ray of the launch 2-3 % (a ballot per iteration, four flags,
 // registers); the host turns it on for the launches that see such rays in numbers: the MIS integrators' bounce stages.
-template <bool REL, bool LOG, int PRUNE, bool GEN, class Hook, bool SEMI = false>
+template <bool REL, bool LOG, int PRUNE, bool GEN, class Hook, bool SEMI = false, bool GS = false>
 EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
   static_assert(!GEN || REL, "generated rays start at the launch's uniform origin");
   extern __shared__ __attribute__((aligned(16))) int lds_stack[];
@@ -237,9 +247,15 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
   // LDS layout: [lane table: BLOCK ints][stack rows][staged records]
   int* stack = lds_stack + BLOCK + threadIdx.x;
   const TraceScene& sc = a.sc;
-  const uint32_t n_rays = (*a.n_paths) * a.rays_per_path;
+  const uint32_t n_real = (*a.n_paths) * a.rays_per_path;
   const int lane = threadIdx.x & 63;
-  if (n_rays == 0) return;
+  if (n_real == 0) return;
+  // (GSCAT: queue positions below are LOGICAL; see TraceQ4Args::gscat_shift.  The logical domain is 256 * R whole granules.)
+  // (granule = 8 slots, a compile-time constant, and R is re-derived from n_rays where it is used: the kernel sits at its
+  // SGPR limit too, and every uniform value kept across the loop is spilled into a VGPR lane)
+  constexpr bool gscat = GS && !GEN && !Hook::PATH;
+  constexpr uint32_t GSH = 3u;
+  const uint32_t n_rays = gscat ? ((((n_real + (1u << GSH) - 1u) >> GSH) + 255u) >> 8) << (8u + GSH) : n_real;
   int* wsrc = lds_stack + (threadIdx.x >> 6) * 64;
   float4* lds_nodes = reinterpret_cast<float4*>(lds_stack + BLOCK + a.stack_entries * BLOCK);
   const float4* inner = REL ? A.inner4_rel : A.inner4;
@@ -423,8 +439,12 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
           pool_next += cnt;
           if (pool_next >= n_rays && pool_end >= n_rays) exhausted = true;
         }
-        if (need && served && idx < n_rays) {
-          uint32_t rs = idx;
+        uint32_t rs = idx;
+        if (gscat) { // logical -> physical queue position (positions past the queue's end hold no ray)
+          const uint32_t g = idx >> GSH;
+          rs = (((g & 255u) * (n_rays >> (8u + GSH)) + (g >> 8)) << GSH) | (idx & ((1u << GSH) - 1u));
+        }
+        if (need && served && idx < n_rays && rs < n_real) {
           if (a.slot_map) rs = a.slot_map[idx];
           nx_slot = rs;
           if (!REL) nx_o = a.const_origin == 1u ? make_float4(a.origin[0], a.origin[1], a.origin[2], 0.0f) : a.rq.o[rs >> (a.const_origin >> 1)];
@@ -752,9 +772,10 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
   }
 }
 
-template <int WPS, bool REL, bool LOG = false, int PRUNE = 0, bool GEN = false, bool SEMI = false>
+// GS: queue positions are drawn in the scattered order (TraceQ4Args::gscat_shift; granules of 8 slots)
+template <int WPS, bool REL, bool LOG = false, int PRUNE = 0, bool GEN = false, bool SEMI = false, bool GS = false>
 __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
-  traceq4_body<REL, LOG, PRUNE, GEN, NoPathHook, SEMI>(A, NoPathHook());
+  traceq4_body<REL, LOG, PRUNE, GEN, NoPathHook, SEMI, GS>(A, NoPathHook());
 }
 
 } // namespace ezd

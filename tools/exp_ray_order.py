@@ -101,6 +101,21 @@ def main():
         k = (cell(16) * 8 + octant)[base]
         blk = np.arange(N) // bsz
         orders["pipeline, batches of %d sorted by cell 16^3 + octant" % bsz] = base[np.lexsort((k, blk))]
+    if os.environ.get("EXP_ORDERS", "") == "granules":   # second round: how fine must the mixing be?  (sorting lost: profiles/r4)
+        orders = {"pipeline (scattered 8x8 sub-blocks)": pipeline, "random": rng.permutation(N)}
+        for g in (8, 16, 32, 64, 128):
+            ng = (N + g - 1) // g
+            pg = rng.permutation(ng)
+            idx = (pg[:, None] * g + np.arange(g)[None, :]).ravel()
+            orders["pipeline, granules of %d rays shuffled" % g] = base[idx[idx < N]]
+        for g, M in ((16, 251), (16, 2531), (32, 251), (8, 251)):
+            ng = (N + g - 1) // g
+            while ng % M == 0:
+                M += 2
+            lg = np.arange(ng)
+            pg = (lg * M) % ng
+            idx = (pg[:, None] * g + np.arange(g)[None, :]).ravel()
+            orders["pipeline, granule of %d -> (granule x %d) mod n" % (g, M)] = base[idx[idx < N]]
     want = None
     for label, o in orders.items():
         r = np.ascontiguousarray(rays[o])
