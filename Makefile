@@ -40,7 +40,7 @@ build/hip/%.o: ezrt_amd/csrc/hip/%.hip $(wildcard ezrt_amd/csrc/hip/*.h) $(wildc
 	$(HIPCC) $(HIP_FLAGS) -c -o $@ $<
 $(LIBDIR)/libezrt_hip.so: $(HIP_OBJ)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(HIP_OBJ) -ldl
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(HIP_OBJ) -ldl -pthread
 
 # Consumers of the public headers outside the libraries: chapter 5's main() ported onto the C ABI + the
 # C++ host API (g++ only: the boundary needs no HIP header), and a C11 layout check of the by-value struct.
@@ -66,4 +66,4 @@ clean:
 # negative on purpose; never loaded by the product (EZRT_HIP_LIB selects it for that one run)
 negctl:
 	@mkdir -p build_ab
-	$(HIPCC) $(HIP_FLAGS) -DEZRT_PRUNE_NEGATIVE_CONTROL=1 -shared -o build_ab/libezrt_hip_negctl.so $(HIP_SRC) -ldl
+	$(HIPCC) $(HIP_FLAGS) -DEZRT_PRUNE_NEGATIVE_CONTROL=1 -shared -o build_ab/libezrt_hip_negctl.so $(HIP_SRC) -ldl -pthread

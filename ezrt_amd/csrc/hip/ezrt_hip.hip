@@ -9,8 +9,10 @@
 #include <cstdlib>
 #include <array>
 #include <cstring>
+#include <chrono>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ezrt.h"
@@ -68,6 +70,7 @@ struct Tuning {
   int packet_budget = 48;  // steps after which a packet hands its rays to the per-lane kernel
   int leaf_threshold = 12; // lanes waiting at a leaf that trigger the triangle phase (24 until the traversal pruned: 12 is +3 % on C3 / C5 now)
   int pool_div = 1;        // ray-index pool = clamp(n_rays / (n_waves * pool_div), 8, pool_max)
+  int pool_min = 8;        // fewest rays a wave is dealt (clamped to pool_max): a short queue then goes to fewer, fuller waves
   int pool_max = 128;      // rays per dynamic reservation (two 8x8 sub-blocks; affordable since the reservations spread over 8 counters)
   int trace_wps_rel = 7;   // waves per SIMD of the primary stage's launch (traceq4_kernel<.., true>; 0: trace_wps).  That variant
                            // needs 79 VGPRs; at 72 it spills 7 and is still 1.5 % faster (seven waves hide more latency)
@@ -162,6 +165,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"leaf_threshold", &Tuning::leaf_threshold, 1, 64},
                               {"pool_div", &Tuning::pool_div, 1, 1 << 16},
                               {"pool_max", &Tuning::pool_max, 8, 4096},
+                              {"pool_min", &Tuning::pool_min, 8, 4096},
                               {"trace_wps", &Tuning::trace_wps, 1, 8},
                               {"trace_wps_rel", &Tuning::trace_wps_rel, 0, 8},
                               {"lds_nodes", &Tuning::lds_nodes, 0, 1 << 24},
@@ -323,6 +327,28 @@ struct EzrtScene {
 
 namespace {
 
+// Host-side loops of ezrt_scene_create over triangles / leaves (round 4: C5's create took 0.3 s on one thread).  Chunks of
+// [0, n) on up to 16 threads; every use writes disjoint elements and reduces with order-independent operations (max, integer
+// sums), so the result does not depend on the thread count.
+template <class F>
+void parallel_for(int n, int grain, F f) {
+  unsigned hw = std::thread::hardware_concurrency();
+  if (const char* e = getenv("EZRT_HOST_THREADS")) hw = (unsigned)std::max(1, atoi(e));
+  int nt = (int)std::min<unsigned>(hw ? hw : 1u, 16u);
+  nt = std::min(nt, std::max(1, n / std::max(1, grain)));
+  if (nt <= 1) {
+    f(0, n, 0);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (int k = 0; k < nt; k++) {
+    const int lo = (int)((long long)n * k / nt), hi = (int)((long long)n * (k + 1) / nt);
+    th.emplace_back([=, &f] { f(lo, hi, k); });
+  }
+  for (auto& t : th) t.join();
+}
+constexpr int PAR_MAX = 16; // threads of parallel_for at most (per-thread partial results are arrays of this size)
+
 struct HostNode {
   int left, right, n, index;
   float AA[3], BB[3];
@@ -354,10 +380,27 @@ HostNode decode_node(const float* nodes, int i) {
 struct LeafPrim {
   float c[3];
   int node, w;
+  float AA[3], BB[3]; // the leaf's box (a copy: the binning loop streams these instead of chasing `node` into the reference's array)
 };
-int retree_build(std::vector<LeafPrim>& pr, int begin, int end, const std::vector<HostNode>& ref, std::vector<HostNode>& out, int depth = 0) {
+inline void retree_union(std::vector<HostNode>& out, int id) { // exact unions: every box is nested in its parent's by construction
+  HostNode& h = out[(size_t)id];
+  for (int k = 0; k < 3; k++) {
+    h.AA[k] = std::min(out[(size_t)h.left].AA[k], out[(size_t)h.right].AA[k]);
+    h.BB[k] = std::max(out[(size_t)h.left].BB[k], out[(size_t)h.right].BB[k]);
+  }
+}
+struct RetreeJob { // a subrange whose subtree is built by another thread and spliced in afterwards
+  int slot, begin, end, depth;
+};
+// jobs (or NULL): ranges of at most `grain` leaves below the first two levels are not built here but listed, their root an empty slot
+int retree_build(std::vector<LeafPrim>& pr, int begin, int end, const std::vector<HostNode>& ref, std::vector<HostNode>& out, int depth = 0,
+                 std::vector<RetreeJob>* jobs = nullptr, int grain = 0) {
   const int id = (int)out.size();
   out.push_back(HostNode());
+  if (jobs && depth >= 2 && end - begin <= grain && end - begin > 1) {
+    jobs->push_back(RetreeJob{id, begin, end, depth});
+    return id;
+  }
   if (end - begin == 1) {
     out[(size_t)id] = ref[(size_t)pr[(size_t)begin].node];
     out[(size_t)id].left = out[(size_t)id].right = 0;
@@ -388,8 +431,8 @@ int retree_build(std::vector<LeafPrim>& pr, int begin, int end, const std::vecto
     for (int i = begin; i < end; i++) {
       int b = (int)((pr[(size_t)i].c[a] - clo[a]) * scale);
       b = b < 0 ? 0 : (b > NB - 1 ? NB - 1 : b);
-      const HostNode& h = ref[(size_t)pr[(size_t)i].node];
-      cnt[b] += pr[(size_t)i].w;
+      const LeafPrim& h = pr[(size_t)i];
+      cnt[b] += h.w;
       for (int k = 0; k < 3; k++) {
         lo[b][k] = std::min(lo[b][k], h.AA[k]);
         hi[b][k] = std::max(hi[b][k], h.BB[k]);
@@ -445,16 +488,13 @@ int retree_build(std::vector<LeafPrim>& pr, int begin, int end, const std::vecto
     std::nth_element(pr.begin() + begin, pr.begin() + mid, pr.begin() + end,
                      [a](const LeafPrim& x, const LeafPrim& y) { return x.c[a] < y.c[a] || (x.c[a] == y.c[a] && x.node < y.node); });
   }
-  const int l = retree_build(pr, begin, mid, ref, out, depth + 1), r = retree_build(pr, mid, end, ref, out, depth + 1);
+  const int l = retree_build(pr, begin, mid, ref, out, depth + 1, jobs, grain), r = retree_build(pr, mid, end, ref, out, depth + 1, jobs, grain);
   HostNode& h = out[(size_t)id];
   h.left = l;
   h.right = r;
   h.n = 0;
   h.index = 0;
-  for (int k = 0; k < 3; k++) { // exact unions: every box is nested in its parent's by construction
-    h.AA[k] = std::min(out[(size_t)l].AA[k], out[(size_t)r].AA[k]);
-    h.BB[k] = std::max(out[(size_t)l].BB[k], out[(size_t)r].BB[k]);
-  }
+  if (!jobs) retree_union(out, id); // (with deferred subtrees below, the unions are taken once they are spliced in: retree_leaves)
   return id;
 }
 // tree[0] dummy, tree[1] root, children after parents; leaves are copies of the reference's reachable leaves
@@ -470,7 +510,11 @@ bool retree_leaves(const std::vector<HostNode>& ref, int n_nodes, std::vector<Ho
     const HostNode& h = ref[(size_t)i];
     if (h.n > 0) {
       LeafPrim q;
-      for (int k = 0; k < 3; k++) q.c[k] = 0.5f * h.AA[k] + 0.5f * h.BB[k];
+      for (int k = 0; k < 3; k++) {
+        q.c[k] = 0.5f * h.AA[k] + 0.5f * h.BB[k];
+        q.AA[k] = h.AA[k];
+        q.BB[k] = h.BB[k];
+      }
       q.node = i;
       q.w = h.n;
       pr.push_back(q);
@@ -486,7 +530,42 @@ bool retree_leaves(const std::vector<HostNode>& ref, int n_nodes, std::vector<Ho
   tree.clear();
   tree.reserve(2 * pr.size() + 1);
   tree.push_back(HostNode());
-  retree_build(pr, 0, (int)pr.size(), ref, tree);
+  // The top of the tree is built here; subtrees of at most 1/32 of the leaves are built by worker threads into vectors of their
+  // own (disjoint ranges of `pr`) and spliced in behind it -- any numbering with children after their parents will do, and
+  // the tree itself does not depend on the thread count (the same splits, the same unions).
+  std::vector<RetreeJob> jobs;
+  const int grain = pr.size() >= 65536 ? (int)(pr.size() / 32) : 0;
+  retree_build(pr, 0, (int)pr.size(), ref, tree, 0, grain ? &jobs : nullptr, grain);
+  if (grain) {
+    std::vector<std::vector<HostNode>> local(jobs.size());
+    parallel_for((int)jobs.size(), 1, [&](int lo, int hi, int) {
+      for (int j = lo; j < hi; j++) {
+        local[(size_t)j].reserve(2 * (size_t)(jobs[(size_t)j].end - jobs[(size_t)j].begin));
+        retree_build(pr, jobs[(size_t)j].begin, jobs[(size_t)j].end, ref, local[(size_t)j], jobs[(size_t)j].depth);
+      }
+    });
+    const int top_count = (int)tree.size(); // nodes made by this thread: ids [1, top_count), the job slots among them
+    std::vector<char> is_job((size_t)top_count, 0);
+    for (const RetreeJob& j : jobs) is_job[(size_t)j.slot] = 1;
+    for (size_t j = 0; j < jobs.size(); j++) { // local index 0 = the job's slot, k > 0 -> base + k - 1
+      const std::vector<HostNode>& L = local[j];
+      const int base = (int)tree.size(), slot = jobs[j].slot;
+      auto map = [&](int k) { return k == 0 ? slot : base + k - 1; };
+      for (size_t k = 0; k < L.size(); k++) {
+        HostNode h = L[k];
+        if (h.n <= 0) {
+          h.left = map(h.left);
+          h.right = map(h.right);
+        }
+        if (k == 0) tree[(size_t)slot] = h;
+        else tree.push_back(h);
+      }
+    }
+    // boxes of the top nodes: children carry larger ids than their parents, so one backward sweep over the inner nodes this
+    // thread made (their unions were postponed: the job slots had no box yet)
+    for (int i = top_count - 1; i >= 1; i--)
+      if (!is_job[(size_t)i] && tree[(size_t)i].n <= 0) retree_union(tree, i);
+  }
   return true;
 }
 
@@ -807,6 +886,7 @@ void fill_trace_knobs(const EzrtScene* s, const TraceCfg& c, TraceQArgs& t) {
   t.refill_min = (uint32_t)(tu.refill_min < 1 ? 1 : (tu.refill_min > 64 ? 64 : tu.refill_min));
   t.pool_div = (uint32_t)(tu.pool_div < 1 ? 1 : tu.pool_div);
   t.pool_max = (uint32_t)(tu.pool_max < (int)TRACE_POOL_MIN ? (int)TRACE_POOL_MIN : (tu.pool_max > 4096 ? 4096 : tu.pool_max));
+  t.pool_min = (uint32_t)(tu.pool_min < (int)TRACE_POOL_MIN ? (int)TRACE_POOL_MIN : (tu.pool_min > (int)t.pool_max ? (int)t.pool_max : tu.pool_min));
   t.stack_entries = (int32_t)(c.lds / (BLOCK * sizeof(int)));
   t.lds_nodes = c.lds_nodes;
   // distance pruning of the binary kernel's in-order traversal (redo launches, wide4 = 0): same margin as traceq4_kernel's
@@ -1374,6 +1454,15 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
   if (n_tri >= (1 << 24) || n_nodes >= (1 << 24))
     return fail(EZRT_ERR_UNSUPPORTED, "counts >= 2^24 are not exact in the float encoding");
   if (n_nodes < 2) return fail(EZRT_ERR_INVALID, "need at least the dummy node 0 and the root node 1");
+  // EZRT_CREATE_TIMING=1: wall time of the host-side phases below, to stderr
+  static const bool timing = getenv("EZRT_CREATE_TIMING") && atoi(getenv("EZRT_CREATE_TIMING")) != 0;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[ezrt] scene_create %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
 
   // ---- validate + measure the tree (pre-order ids: child > parent)
   std::vector<int> depth((size_t)n_nodes, 0), inner_id((size_t)n_nodes, -1);
@@ -1437,6 +1526,7 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
       if (inner_id[(size_t)i] >= 0 && !seen[(size_t)i]) order.push_back(i);
     for (size_t q = 0; q < order.size(); q++) inner_id[(size_t)order[q]] = (int)q;
   }
+  lap("validate + numbering");
   auto ref_of = [&](int node) -> uint32_t {
     HostNode h = decode_node(nodes, node);
     if (h.n > 0) return LEAF_BIT | ((uint32_t)(h.n - 1) << 24) | (uint32_t)h.index;
@@ -1457,6 +1547,7 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
     memcpy(&rf, &rr, 4);
     q[3] = make_float4(lf, rf, 0.0f, 0.0f);
   }
+  lap("binary records");
   // ---- 4-wide collapse for traceq4_kernel (ezrt_traceq4.h).  Valid only when every box is nested in its
   // parent's box (true for the reference builders; checked here because the arrays are the caller's).
   std::vector<float4> inner4;
@@ -1467,6 +1558,7 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
   {
     std::vector<HostNode> hn((size_t)n_nodes);
     for (int i = 1; i < n_nodes; i++) hn[(size_t)i] = decode_node(nodes, i);
+    lap("  decode nodes");
     bool nested = inner_id[1] >= 0;
     // caller arrays may be a DAG (an inner node referenced by several parents: validation only asks parent < child).
     // The collapse below makes one record per (parent, inner child) visit and indexes records by node, so a shared
@@ -1494,6 +1586,7 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
     for (int attempt = 0; nested && attempt < 2; attempt++) {
       retreed = attempt == 0 && tuning_from_env().retree != 0 && retree_leaves(hn, n_nodes, tree4);
       if (!retreed) tree4 = hn; // (node ids = the caller's)
+      lap("  retree_leaves");
       auto is_inner = [&](int i) { return tree4[(size_t)i].n <= 0; };
       auto area = [&](int i) { // schedule heuristic only
         const HostNode& h = tree4[(size_t)i];
@@ -1558,6 +1651,7 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
         for (int j = 0; j < r.m; j++) w = std::max(w, r.m - 1 - j + nd[j]);
         need[q] = w;
       }
+      lap("  cuts + stack need");
       stack_need4 = std::max(1, need[0]);
       // breadth-first numbering: the top of the tree is a prefix (staged in LDS)
       std::vector<int> order(1, 0), number(recs.size(), -1);
@@ -1604,6 +1698,7 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
       if (!retreed || ((size_t)stack_need4 + 4) * BLOCK * sizeof(int) <= 60 * 1024) break; // (the bound of use_wide4)
     }
   }
+  lap("re-tree + 4-wide collapse");
   // ---- tables of tie_precedes (ezrt_traceq4.h): only for arrays that are a tree with nested boxes (the 4-wide records exist)
   // and whose leaves do not share triangles
   std::vector<int32_t> tri_leaf_h;
@@ -1636,8 +1731,10 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
         if (v < 0) v = 1; // (triangles no leaf holds are never tested)
     }
   }
+  lap("tie tables");
   std::vector<float4> geom((size_t)n_tri * 3);
-  for (int i = 0; i < n_tri; i++) {
+  parallel_for(n_tri, 1 << 15, [&](int lo_i, int hi_i, int) {
+  for (int i = lo_i; i < hi_i; i++) {
     const float* t = tri + (size_t)i * EZRT_TRI_FLOATS;
     // N = normalize(cross(p2 - p1, p3 - p1)), P5/fsh:172 -- same fp32 ops, contraction off
     float e1x = t[3] - t[0], e1y = t[4] - t[1], e1z = t[5] - t[2];
@@ -1648,7 +1745,9 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
     geom[(size_t)i * 3 + 1] = make_float4(t[3], t[4], t[5], cy * inv);
     geom[(size_t)i * 3 + 2] = make_float4(t[6], t[7], t[8], cz * inv);
   }
+  });
 
+  lap("geometry records");
   // ---- distance pruning (ezrt_traceq4.h "Distance pruning"): the per-triangle bound eta_T in double precision, A = 2 max
   // eta_T over the triangles below each slot (row 7 of the 4-wide records).  Leaf boxes must hold their triangles (true for
   // the reference builders; these are the caller's arrays).
@@ -1668,10 +1767,16 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
       }
     }
   }
+  lap("  leaf boxes hold their triangles");
   if (prunable) {
     const double eps = 1.0 / 16777216.0, dinf = (double)__builtin_inff();
     std::vector<double> eta((size_t)n_tri, 0.0);
-    for (int i = 0; i < n_tri; i++) {
+    double part_M[PAR_MAX] = {0}, part_G[PAR_MAX] = {0}, part_Z[PAR_MAX] = {0}; // per-thread maxima and counts (order-independent)
+    int64_t part_bad[PAR_MAX] = {0};
+    parallel_for(n_tri, 1 << 14, [&](int lo_i, int hi_i, int tid) {
+    double prune_M = 0.0, prune_G = 0.0, prune_Z = 0.0; // (this thread's)
+    int64_t prune_bad = 0;
+    for (int i = lo_i; i < hi_i; i++) {
       const float* t = tri + (size_t)i * EZRT_TRI_FLOATS;
       double p[3][3], n[3] = {(double)geom[(size_t)i * 3].w, (double)geom[(size_t)i * 3 + 1].w, (double)geom[(size_t)i * 3 + 2].w}, m_t = 0.0;
       for (int v = 0; v < 3; v++)
@@ -1718,6 +1823,18 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
       prune_G = __builtin_fmax(prune_G, 1.0 / smin);
       prune_Z = __builtin_fmax(prune_Z, zeta);
     }
+    part_M[tid] = prune_M;
+    part_G[tid] = prune_G;
+    part_Z[tid] = prune_Z;
+    part_bad[tid] = prune_bad;
+    });
+    for (int k = 0; k < PAR_MAX; k++) {
+      prune_M = __builtin_fmax(prune_M, part_M[k]);
+      prune_G = __builtin_fmax(prune_G, part_G[k]);
+      prune_Z = __builtin_fmax(prune_Z, part_Z[k]);
+      prune_bad += part_bad[k];
+    }
+  lap("  eta loop");
     // ordinary triangles: eta_T <= cutoff.  cutoff = 2^-13 max|coordinate| when that already leaves a margin that is small
     // at the scale the geometry lives on (<= 2^-14 of the median triangle's largest coordinate); otherwise -- a ground
     // plane of kilometres under a metre-sized model -- the 1 - 2^-10 quantile of the bounds.  The others flag every node above them.
@@ -1741,6 +1858,7 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
         cutoff = __builtin_fmin(cutoff, all[k]);
       }
     }
+  lap("  cutoff quantile");
     double a_max = 0.0;
     std::vector<double> fin;
     for (int i = 0; i < n_tri; i++) {
@@ -1756,6 +1874,7 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
       prune_A_med = 2.0 * fin[fin.size() / 2];
     }
     prune_a = __builtin_nextafterf((float)(2.0 * a_max), __builtin_inff());
+  lap("  a_max");
     std::vector<unsigned char> node_flag(tree4.size(), 0); // (ids are topologically ordered: children after parents)
     for (int i = (int)tree4.size() - 1; i >= 1; i--) {
       const HostNode& h = tree4[(size_t)i];
@@ -1806,14 +1925,22 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
     if (root4_flag) prune_flagged++;
   }
 
+  lap("pruning bounds + flags");
   // ---- shading records + table of distinct materials (bitwise distinct 18-float tuples)
   std::vector<float4> shade((size_t)n_tri * SHADE_REC_FLOAT4), mats;
   {
     std::map<std::array<uint32_t, 18>, uint32_t> index;
-    for (int i = 0; i < n_tri; i++) {
+    std::vector<uint32_t> mat_id((size_t)n_tri);
+    std::array<uint32_t, 18> last_key;
+    uint32_t last_id = 0;
+    for (int i = 0; i < n_tri; i++) { // (sequential: material numbers follow first appearance; consecutive triangles mostly share one)
       const float* t = tri + (size_t)i * EZRT_TRI_FLOATS;
       std::array<uint32_t, 18> key;
       memcpy(key.data(), t + 18, sizeof(uint32_t) * 18);
+      if (i > 0 && key == last_key) {
+        mat_id[(size_t)i] = last_id;
+        continue;
+      }
       auto it = index.find(key);
       if (it == index.end()) {
         it = index.emplace(key, (uint32_t)index.size()).first;
@@ -1839,9 +1966,16 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
         mats.push_back(make_float4(m.Cspec0.z, m.Csheen.x, m.Csheen.y, m.Csheen.z));
         mats.push_back(make_float4(m.alpha_gtr2, m.alpha_gtr1, m.gtr1_a2m1, m.gtr1_pilog));
       }
+      last_key = key;
+      last_id = it->second;
+      mat_id[(size_t)i] = last_id;
+    }
+    parallel_for(n_tri, 1 << 15, [&](int lo_i, int hi_i, int) {
+    for (int i = lo_i; i < hi_i; i++) {
+      const float* t = tri + (size_t)i * EZRT_TRI_FLOATS;
       const ShadeDen dn = shade_denominators(f3{t[0], t[1], t[2]}, f3{t[3], t[4], t[5]}, f3{t[6], t[7], t[8]});
       float mi;
-      const uint32_t mu = it->second;
+      const uint32_t mu = mat_id[(size_t)i];
       memcpy(&mi, &mu, 4);
       float4* o = &shade[(size_t)i * SHADE_REC_FLOAT4];
       o[0] = make_float4(t[9], t[10], t[11], t[12]);
@@ -1849,8 +1983,10 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
       o[2] = make_float4(t[17], mi, 0.0f, 0.0f);
       o[3] = make_float4(dn.a5, dn.b5, dn.a34, dn.b34);
     }
+    });
   }
 
+  lap("shading records");
   EzrtScene* s = new (std::nothrow) EzrtScene();
   if (!s) return fail(EZRT_ERR_NOMEM, "out of memory");
   s->n_tri = n_tri;
@@ -1902,6 +2038,7 @@ int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nod
   }
   SC_TRY(hipMemset(s->counters.p, 0, (size_t)CTR_SLOTS * EZRT_CTR_COUNT * sizeof(unsigned long long)));
 #undef SC_TRY
+  lap("device allocation + upload");
   s->stats[0] = n_tri;
   s->stats[1] = n_nodes;
   s->stats[2] = maxd;

@@ -62,7 +62,8 @@ struct TraceQArgs {
   int32_t leaf_threshold;  // lanes waiting at a leaf that trigger the triangle phase
   uint32_t refill_min;     // lanes that must be free before the wave runs its refill code
   uint32_t static_pct;     // share of the queue dealt statically (interleaved rounds of pools), percent
-  uint32_t pool_div, pool_max; // pool = clamp(n_rays / (n_waves * pool_div), 8, pool_max)
+  uint32_t pool_div, pool_max; // pool = clamp(n_rays / (n_waves * pool_div), pool_min, pool_max)
+  uint32_t pool_min;           // >= TRACE_POOL_MIN: a short queue is dealt to fewer waves, this many rays each (the others retire at once)
   int32_t lds_nodes;       // inner records [0, lds_nodes) staged in LDS (after stack + lane table)
   int32_t stack_entries;   // LDS stack rows (tree depth); the per-wave lane table follows them
   uint32_t* dbg;           // diagnostic (FULLCTR only): [0] max pops/ray [1] max tris/ray [2] max iterations/ray
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
   // and cheap pools.  Indices beyond the static region are reserved dynamically, one atomic per pool, on eight counters.
   // (Smaller pools only for the queue's last stretch, and guided pool sizes, were tried: no gain.)
   uint32_t pool_size = (n_rays + n_waves * a.pool_div - 1) / (n_waves * a.pool_div);
-  pool_size = pool_size > a.pool_max ? a.pool_max : (pool_size < TRACE_POOL_MIN ? TRACE_POOL_MIN : pool_size);
+  pool_size = pool_size > a.pool_max ? a.pool_max : (pool_size < a.pool_min ? a.pool_min : pool_size);
   uint32_t static_rounds = (uint32_t)(((unsigned long long)n_rays * a.static_pct) / (100ull * n_waves * pool_size));
   static_rounds = static_rounds < 1u ? 1u : static_rounds;
   const uint32_t static_total = static_rounds * n_waves * pool_size;

@@ -265,7 +265,7 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
   // queue indices: see ezrt_traceq.h
   const uint32_t n_waves = gridDim.x * (BLOCK / 64);
   uint32_t pool_size = (n_rays + n_waves * a.pool_div - 1) / (n_waves * a.pool_div);
-  pool_size = pool_size > a.pool_max ? a.pool_max : (pool_size < TRACE_POOL_MIN ? TRACE_POOL_MIN : pool_size);
+  pool_size = pool_size > a.pool_max ? a.pool_max : (pool_size < a.pool_min ? a.pool_min : pool_size);
   uint32_t static_rounds = (uint32_t)(((unsigned long long)n_rays * a.static_pct) / (100ull * n_waves * pool_size));
   static_rounds = static_rounds < 1u ? 1u : static_rounds;
   const uint32_t static_total = static_rounds * n_waves * pool_size;

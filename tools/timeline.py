@@ -10,7 +10,7 @@ for r in rows:
         continue
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     seq.append((n.split("ezd::")[1][:34], (e - s) / 1e3, s, e))
-start = [i for i, o in enumerate(seq) if o[0].startswith("raygen")]
+start = [i for i, o in enumerate(seq) if o[0].startswith("raygen") or o[0].startswith("chunk_prologue")]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 i0, i1 = start[which], start[which + 1]
 prev = None
