@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""tools/summarize_config_profile.py CFG <gpurun_out/profcfg_CFG> <out dir>: the raw rocprofv3 output of tools/profile_configs.sh ->
+<out dir>/<cfg>_kernel_stats.csv (as rocprofv3 wrote it) and <cfg>_pmc_summary.json: per kernel -- calls, average and total time,
+share of the GPU time, VALU wave-instructions per dispatch, issue rate (T wave-instr/s) and its fraction of the measured 1.086 T /
+nominal 1.229 T peaks, lane fill, share of wave-cycles waiting, HBM bytes ((2 FETCH_SIZE + WRITE_SIZE) KB, gfx950 correction of
+MI355X_MICROARCH.md) and HBM GB/s, L1 -> L2 read requests; stamped with the hash of the GPU sources."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ezrt_amd.srchash import gpu_source_hash  # noqa: E402
+
+
+def short(name):
+    n = name.split("ezd::", 1)[1] if "ezd::" in name else name
+    return n.split("(")[0]
+
+
+def main():
+    cfg, src, dst = sys.argv[1], sys.argv[2], sys.argv[3]
+    os.makedirs(dst, exist_ok=True)
+    stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    dur = {}
+    total = 0.0
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, cfg.lower() + "_kernel_stats.csv"))
+        for r in csv.DictReader(open(stats[0])):
+            if "ezd::" not in r["Name"]:
+                continue
+            dur[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]), float(r["TotalDurationNs"]))
+            total += float(r["TotalDurationNs"])
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in sorted(glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
+        for r in csv.DictReader(open(f)):
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    kernels = {}
+    for k, (calls, avg_ns, tot_ns) in sorted(dur.items(), key=lambda kv: -kv[1][2]):
+        c = {n: sum(v) / len(v) for n, v in agg.get(k, {}).items()}
+        e = {"calls": calls, "avg_us": round(avg_ns / 1e3, 2), "total_ms": round(tot_ns / 1e6, 3), "share_of_gpu_time": round(tot_ns / total, 4) if total else None}
+        if "SQ_INSTS_VALU" in c and avg_ns > 0:
+            rate = c["SQ_INSTS_VALU"] / (avg_ns * 1e-9) / 1e12
+            e.update({"valu_wave_instr_per_dispatch": int(c["SQ_INSTS_VALU"]), "issue_rate_T": round(rate, 4),
+                      "issue_frac_of_measured_peak_1.086": round(rate / 1.086, 4), "issue_frac_of_nominal_peak_1.229": round(rate / 1.2288, 4)})
+            if "SQ_THREAD_CYCLES_VALU" in c:
+                e["lane_fill"] = round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"]), 4)
+        if c.get("SQ_WAVE_CYCLES"):
+            e["wave_cycles_waiting"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4)
+        if "FETCH_SIZE" in c and avg_ns > 0:
+            hbm = (2.0 * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024.0
+            e.update({"hbm_bytes_per_dispatch": int(hbm), "hbm_GBs": round(hbm / (avg_ns * 1e-9) / 1e9, 1), "hbm_frac_of_8TBs": round(hbm / (avg_ns * 1e-9) / 8e12, 4)})
+        if "TCP_TCC_READ_REQ_sum" in c:
+            e["l1_to_l2_read_requests"] = int(c["TCP_TCC_READ_REQ_sum"])
+            e["l1_accesses"] = int(c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0))
+        kernels[k] = e
+    trace_share = sum(v["share_of_gpu_time"] or 0 for k, v in kernels.items() if k.startswith("traceq"))
+    out = {"config": cfg, "command": "tools/config_one.py %s at the BASELINE spp (tools/profile_configs.sh)" % cfg, "source_sha": gpu_source_hash(),
+           "gpu_time_ms_all_ezd_kernels": round(total / 1e6, 3), "trace_kernels_share_of_gpu_time": round(trace_share, 4),
+           "hbm_correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md: gfx950 FETCH_SIZE tallies 128-B requests at 64 B)",
+           "kernels": kernels}
+    json.dump(out, open(os.path.join(dst, cfg.lower() + "_pmc_summary.json"), "w"), indent=1)
+    print(cfg, "GPU time %.1f ms, trace share %.2f;" % (total / 1e6, trace_share),
+          "; ".join("%s %.0f us x%d" % (k[:40], v["avg_us"], v["calls"]) for k, v in list(kernels.items())[:5]))
+
+
+if __name__ == "__main__":
+    main()
