@@ -126,7 +126,8 @@ struct Tuning {
   int env_planes = 1;      // the env cache as an (x, y) plane and a pdf plane for bilinear lookups (one load per row)
   int env_rgbe = 1;        // environment lookups through the 4-byte RGBE form of the map when it has an exact one (set_env)
   int min_staged = 16;      // a trace launch gives up workgroups per CU (down to 4) until this many top-of-tree records fit in LDS
-  int rel_min_records = 24; // the primary stage runs at trace_wps_rel waves per SIMD only while that leaves this many top-of-tree records in LDS
+  int rel_min_records = 4;  // the primary stage runs at trace_wps_rel waves per SIMD only while that leaves this many top-of-tree records in LDS
+                            // (24 until round 4; C2 and C4 -- 16 stack rows, 6 records left at 7 workgroups per CU -- gain 0.6-1.1 % at 7)
   int gen_primary = 1;     // primary rays are generated inside the primary stage's trace and shading kernels (primary_dir) instead of
                            // written to a queue by raygen_kernel (timed pipeline with the 4-wide, eye-relative records only)
   int anyhit = 1;          // env shadow rays (the even slots of the MIS integrators' bounce stages) stop at their first accepted hit:

@@ -26,7 +26,10 @@ namespace ezd {
 
 constexpr uint32_t REF_NONE = 0xffffffffu; // a lane without a ray (every predicate below is ONE compare on `ref`)
 constexpr uint32_t REF_DONE = 0xfffffffeu; // traversal finished, {t, triangle} not stored yet (done in the batched refill)
-constexpr uint32_t TRACE_HEADS = 8;        // reservation counters per queue
+#ifndef EZRT_TRACE_HEADS
+#define EZRT_TRACE_HEADS 8
+#endif
+constexpr uint32_t TRACE_HEADS = EZRT_TRACE_HEADS; // reservation counters per queue (-DEZRT_TRACE_HEADS=n: A/B builds, tools/build_variant.sh)
 constexpr uint32_t TRACE_HEAD_STRIDE = 16; // words between them (64 bytes)
 constexpr uint32_t TRACE_POOL_MIN = 8; // smallest reservation: short queues are spread over every wave
 

@@ -36,30 +36,49 @@ def main():
             dur[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]), float(r["TotalDurationNs"]))
             total += float(r["TotalDurationNs"])
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in sorted(glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
-        for r in csv.DictReader(open(f)):
-            agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    pdur = collections.defaultdict(dict)     # kernel -> counter -> average duration (ns) of the kernel IN THE PASS that collected the counter
+    for d in sorted(glob.glob(os.path.join(src, "pmc*"))):
+        if not os.path.isdir(d):
+            continue
+        names = set()
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                names.add(r["Counter_Name"])
+        kd = collections.defaultdict(list)
+        for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                kd[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        for k, v in kd.items():
+            for n in names:
+                pdur[k][n] = sum(v) / len(v)
     kernels = {}
     for k, (calls, avg_ns, tot_ns) in sorted(dur.items(), key=lambda kv: -kv[1][2]):
         c = {n: sum(v) / len(v) for n, v in agg.get(k, {}).items()}
         e = {"calls": calls, "avg_us": round(avg_ns / 1e3, 2), "total_ms": round(tot_ns / 1e6, 3), "share_of_gpu_time": round(tot_ns / total, 4) if total else None}
-        if "SQ_INSTS_VALU" in c and avg_ns > 0:
-            rate = c["SQ_INSTS_VALU"] / (avg_ns * 1e-9) / 1e12
+        pd = pdur.get(k, {})
+        if "SQ_INSTS_VALU" in c and pd.get("SQ_INSTS_VALU", 0) > 0:
+            e["avg_us_in_counter_pass"] = round(pd["SQ_INSTS_VALU"] / 1e3, 2)
+            rate = c["SQ_INSTS_VALU"] / (pd["SQ_INSTS_VALU"] * 1e-9) / 1e12
             e.update({"valu_wave_instr_per_dispatch": int(c["SQ_INSTS_VALU"]), "issue_rate_T": round(rate, 4),
                       "issue_frac_of_measured_peak_1.086": round(rate / 1.086, 4), "issue_frac_of_nominal_peak_1.229": round(rate / 1.2288, 4)})
             if "SQ_THREAD_CYCLES_VALU" in c:
                 e["lane_fill"] = round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"]), 4)
         if c.get("SQ_WAVE_CYCLES"):
             e["wave_cycles_waiting"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4)
-        if "FETCH_SIZE" in c and avg_ns > 0:
+        if "FETCH_SIZE" in c and pd.get("FETCH_SIZE", 0) > 0:
             hbm = (2.0 * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024.0
-            e.update({"hbm_bytes_per_dispatch": int(hbm), "hbm_GBs": round(hbm / (avg_ns * 1e-9) / 1e9, 1), "hbm_frac_of_8TBs": round(hbm / (avg_ns * 1e-9) / 8e12, 4)})
+            sec = pd["FETCH_SIZE"] * 1e-9
+            e.update({"hbm_bytes_per_dispatch_in_counter_pass": int(hbm), "hbm_GBs": round(hbm / sec / 1e9, 1), "hbm_frac_of_8TBs": round(hbm / sec / 8e12, 4)})
         if "TCP_TCC_READ_REQ_sum" in c:
             e["l1_to_l2_read_requests"] = int(c["TCP_TCC_READ_REQ_sum"])
             e["l1_accesses"] = int(c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0))
         kernels[k] = e
     trace_share = sum(v["share_of_gpu_time"] or 0 for k, v in kernels.items() if k.startswith("traceq"))
     out = {"config": cfg, "command": "tools/config_one.py %s at the BASELINE spp (tools/profile_configs.sh)" % cfg, "source_sha": gpu_source_hash(),
+           "note": "kernel times and shares: rocprofv3 --kernel-trace --stats of the config at its BASELINE spp; counters: separate --pmc passes at one "
+                   "chunk's worth of frames (same kernels, per-dispatch work smaller by the spp ratio for the per-chunk stages) -- the issue rate of a "
+                   "kernel is its counters' VALU instructions / its average duration IN THE SAME pass",
            "gpu_time_ms_all_ezd_kernels": round(total / 1e6, 3), "trace_kernels_share_of_gpu_time": round(trace_share, 4),
            "hbm_correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md: gfx950 FETCH_SIZE tallies 128-B requests at 64 B)",
            "kernels": kernels}
