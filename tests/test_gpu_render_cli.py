@@ -105,4 +105,6 @@ def test_c1_cornell_box_as_stated_through_the_scene_file(hip, oracle, tmp_path):
     png = _read_png_rgb8(tmp_path / "c1.png")
     want8 = oracle.tonemap(want.reshape(-1, 4)).reshape(256, 256, 3)[::-1]      # (PNG rows go top first)
     assert png.shape == (256, 256, 3) and np.array_equal(png, want8)
-    assert (png.max(axis=2) > 0).mean() > 0.5 and len(np.unique(png.reshape(-1, 3), axis=0)) > 50   # walls lit by the light: not a black frame
+    # not a black frame: at ONE sample per pixel the light's own pixels (emission 12 -> saturated) and the few paths that found it
+    lit = png.max(axis=2) > 0
+    assert 0.01 < lit.mean() < 0.9 and int(png.max()) == 255 and len(np.unique(png.reshape(-1, 3), axis=0)) > 20
