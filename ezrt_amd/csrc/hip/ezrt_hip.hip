@@ -60,7 +60,8 @@ struct DevBuf {
   }
 };
 
-constexpr int MAX_TRACE_EVENTS = 64;
+constexpr int MAX_TRACE_EVENTS = 2048; // launch_events: pairs of timing events a call can record (C5 at 512 spp: 576 trace launches);
+                                       // the first 64 are created with the scene's other events, the rest when a call first needs them
 
 // Schedule knobs (never change results).  Defaults = the tuned values for C2 on MI355X; an
 // environment variable EZRT_<NAME> overrides the default at scene creation, ezrt_set_option at run time.
@@ -301,7 +302,7 @@ struct EzrtScene {
   // timing
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   hipEvent_t ev_trace[MAX_TRACE_EVENTS][2];
-  int n_trace_events = 0, n_trace_launches = 0;
+  int n_trace_events = 0, n_trace_launches = 0, n_trace_events_created = 0;
   bool timed = false;
 
   DevScene dev() const {
@@ -638,10 +639,11 @@ int ensure_events(EzrtScene* s) {
   if (s->ev_begin) return 0;
   HIP_TRY(hipEventCreate(&s->ev_begin));
   HIP_TRY(hipEventCreate(&s->ev_end));
-  for (int i = 0; i < MAX_TRACE_EVENTS; i++) {
+  for (int i = 0; i < 64; i++) {
     HIP_TRY(hipEventCreate(&s->ev_trace[i][0]));
     HIP_TRY(hipEventCreate(&s->ev_trace[i][1]));
   }
+  s->n_trace_events_created = 64;
   for (Pipe& q : s->pipe) {
     // (from the process-wide pool: ezrt_streams.h says why the library never destroys a stream)
     HIP_TRY(ezh::stream_acquire(false, &q.stream, &q.stream_device));
@@ -1240,7 +1242,14 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     const bool overlap_redo = wide && split_here && tu.redo_overlap && !full && !plog && !debug_stages && !(b == 0 && use_packet);
     hipEvent_t ev_between = nullptr;
     int e = tu.launch_events ? s->n_trace_events : MAX_TRACE_EVENTS;
-    if (e < MAX_TRACE_EVENTS) HIP_TRY(hipEventRecord(s->ev_trace[e][0], st));
+    if (e < MAX_TRACE_EVENTS) {
+      while (s->n_trace_events_created <= e) { // (calls with more than 64 timed launches: created on first use)
+        HIP_TRY(hipEventCreate(&s->ev_trace[s->n_trace_events_created][0]));
+        HIP_TRY(hipEventCreate(&s->ev_trace[s->n_trace_events_created][1]));
+        s->n_trace_events_created++;
+      }
+      HIP_TRY(hipEventRecord(s->ev_trace[e][0], st));
+    }
     if (b == 0 && !full && use_packet) {
       // primary rays: packet traversal (one wave = one 8x8 tile); rays with an exact distance tie and
       // rays of over-budget packets go to a redo list that the per-lane kernel traces in reference order
@@ -2066,7 +2075,7 @@ void ezrt_scene_destroy(EzrtScene* s) {
       if (q.ev_done) (void)hipEventDestroy(q.ev_done);
       if (q.ev_free) (void)hipEventDestroy(q.ev_free);
     }
-    for (int i = 0; i < MAX_TRACE_EVENTS; i++) {
+    for (int i = 0; i < s->n_trace_events_created; i++) {
       (void)hipEventDestroy(s->ev_trace[i][0]);
       (void)hipEventDestroy(s->ev_trace[i][1]);
     }
@@ -2218,9 +2227,9 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
         a.log_colour = nullptr;
         a.stack_entries = s->depth;
         int e = s->n_trace_events;
-        if (e < MAX_TRACE_EVENTS) HIP_TRY(hipEventRecord(s->ev_trace[e][0], st));
+        if (e < s->n_trace_events_created) HIP_TRY(hipEventRecord(s->ev_trace[e][0], st));
         launch_trace(a, s->instr > 0 ? 1 : 0, dim3((unsigned)((size_t)nb * nf)), lds, st);
-        if (e < MAX_TRACE_EVENTS) {
+        if (e < s->n_trace_events_created) {
           HIP_TRY(hipEventRecord(s->ev_trace[e][1], st));
           s->n_trace_events++;
         }
