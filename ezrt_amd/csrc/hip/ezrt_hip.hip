@@ -151,6 +151,9 @@ struct Tuning {
   int bounce_scatter = 1;  // the bounce stages' trace launches draw their queue in a scattered order, in granules of 8 rays
                            // (TraceQ4Args::gscat_shift; 0: consecutive slots, the order the shading stage wrote; 1: queues with one
                            // ray per path; 2: the MIS integrators' two-ray queues too -- measured slower there)
+  int pipeline_calls = 1;  // consecutive chunks -- of one call or of consecutive calls -- alternate between the two scratch sets and their own
+                           // streams, so that a chunk's latency-bound late stages run under the next chunk's primary stage; only the
+                           // accumulation into the caller's frame buffer stays on the caller's stream, in order (ezrt_render_device)
   int audit_via_queue = 0; // 1: ezrt_query_hits and ezrt_render_paths run through the TIMED kernels (traceq_kernel with
                            // the template, LDS layout, stealing and redo launch of a render call + the streaming shading
                            // stages) instead of the in-order audit kernels; 2 (query only): additionally treat the rays as
@@ -207,6 +210,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"stack_cap", &Tuning::stack_cap, 0, 64},
                               {"debug_stack_cap", &Tuning::debug_stack_cap, 0, 64},
                               {"bounce_scatter", &Tuning::bounce_scatter, 0, 2},
+                              {"pipeline_calls", &Tuning::pipeline_calls, 0, 1},
                               {"audit_via_queue", &Tuning::audit_via_queue, 0, 2}};
 Tuning tuning_from_env() {
   Tuning t;
@@ -248,6 +252,7 @@ struct Pipe {
   hipStream_t stream = nullptr;  // own stream (pipelined calls only)
   hipEvent_t ev_done = nullptr;  // samples of the sub-chunk are complete
   hipEvent_t ev_free = nullptr;  // ... and have been folded into the frame buffer
+  bool free_recorded = false;    // ev_free has been recorded at least once (pipeline_calls: the next user of this scratch set waits for it)
 };
 
 struct EzrtScene {
@@ -297,6 +302,7 @@ struct EzrtScene {
   // persistent trace launches, the late bounces, launch gaps) run under the other's bulk work.
   Pipe pipe[2];
   int num_cus = 0;
+  uint32_t chunk_seq = 0;     // chunks rendered so far (pipeline_calls: chunk i uses scratch set i & 1)
   int n_inner = 0;
   Tuning tune = tuning_from_env();
   // timing
@@ -973,6 +979,7 @@ hipError_t ensure_chunk_scratch(EzrtScene* s, Pipe& pp, size_t n_slots, bool mis
   if (pp.redo_flag.n < n_rays_max) { // zeroed once; every entry set is cleared again by the redo launch
     EZ_ENSURE(pp.redo_flag.ensure(n_rays_max));
     EZ_ENSURE(hipMemsetAsync(pp.redo_flag.p, 0, n_rays_max * sizeof(uint32_t), st));
+    EZ_ENSURE(hipStreamSynchronize(st)); // (the chunk may run on another stream than `st`: pipeline_calls; growth is rare)
   }
   EZ_ENSURE(pp.defer_list.ensure(n_slots + (size_t)2048 * 1024)); // per-workgroup regions: iterations x SHADE_BLOCK each
   EZ_ENSURE(pp.defer_count.ensure(2048u * 1024u / SHADE_BLOCK));
@@ -2187,11 +2194,21 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
       if (s->tune.sub_frames > 0 && (size_t)s->tune.sub_frames < half) half = (size_t)s->tune.sub_frames;
       if (chunk > half) chunk = half;
     }
+    // Chunks pipelined ACROSS calls (knob pipeline_calls, round 4): chunk i of the scene's life runs on scratch set i & 1 and that
+    // set's own stream.  Nothing it does touches the caller's memory -- it reads the scene and writes its own queues and samples --
+    // so it need not wait for anything the caller queued before this call; the kernel that DOES touch the caller's frame buffer,
+    // accumulate_kernel, stays on the caller's stream, after a wait for the chunk's samples, so the frame buffer sees the calls
+    // in the order they were made and everything the caller queues behind a call finds it complete.  A scratch set is reused
+    // only after the accumulation that read its samples (ev_free).  What it buys: the small late stages of a chunk last as long as
+    // their deepest rays (section 6 of DESIGN.md) and leave most of the chip idle; the next chunk's primary stage now runs under
+    // them.  Two independent scenes on two streams showed the potential first: C2 +10-11 % aggregate, C4 +-0 (tools/exp_two_streams.py).
+    const bool xcall = !use_mega && n_pipes == 1 && s->tune.pipeline_calls && !s->tune.debug_stages;
+    const int n_scratch = xcall ? 2 : n_pipes;
     if (!use_mega) { // size the chunk's queues now: if they do not fit, halve the chunk (same results, more launches)
       const bool mis = p->integrator == EZRT_INTEGRATOR_P5_MIS || p->integrator == EZRT_INTEGRATOR_P5_MIS_ANISO;
       for (;;) {
         hipError_t e = hipSuccess;
-        for (int i = 0; i < n_pipes && e == hipSuccess; i++) e = ensure_chunk_scratch(s, s->pipe[i], per_frame * chunk, mis, st);
+        for (int i = 0; i < n_scratch && e == hipSuccess; i++) e = ensure_chunk_scratch(s, s->pipe[i], per_frame * chunk, mis, st);
         if (e == hipSuccess) break;
         (void)hipGetLastError();
         if (e != hipErrorOutOfMemory || chunk <= 1)
@@ -2207,10 +2224,12 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
     uint32_t k = 0;
     for (uint32_t done = 0; done < p->spp; k++) {
       uint32_t nf = (uint32_t)((p->spp - done < chunk) ? (p->spp - done) : chunk);
-      Pipe& q = s->pipe[n_pipes == 2 ? (k & 1u) : 0u];
-      hipStream_t qs = n_pipes == 2 ? q.stream : st;
+      Pipe& q = s->pipe[xcall ? (s->chunk_seq & 1u) : (n_pipes == 2 ? (k & 1u) : 0u)];
+      hipStream_t qs = (xcall || n_pipes == 2) ? q.stream : st;
       HIP_TRY(q.samples.ensure(per_frame * chunk));
-      if (n_pipes == 2) { // after everything queued before the call and after this pipe's previous sub-chunk was consumed
+      if (xcall) { // after the accumulation that consumed this scratch set's previous samples (two chunks ago)
+        if (q.free_recorded) HIP_TRY(hipStreamWaitEvent(qs, q.ev_free, 0));
+      } else if (n_pipes == 2) { // after everything queued before the call and after this pipe's previous sub-chunk was consumed
         HIP_TRY(hipStreamWaitEvent(qs, k < 2 ? s->ev_begin : q.ev_free, 0));
       }
       if (use_mega) {
@@ -2238,7 +2257,7 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
         rc = wavefront_chunk(s, q, p, nb, p->frame0 + done, nf, qs);
         if (rc) return rc;
       }
-      if (n_pipes == 2) { // the running mean is applied in frame order, on the caller's stream
+      if (xcall || n_pipes == 2) { // the running mean is applied in frame order, on the caller's stream
         HIP_TRY(hipEventRecord(q.ev_done, qs));
         HIP_TRY(hipStreamWaitEvent(st, q.ev_done, 0));
       }
@@ -2251,7 +2270,11 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
       b.samples = q.samples.p;
       b.accum = reinterpret_cast<float4*>(accum_dev);
       hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, st, b);
-      if (n_pipes == 2) HIP_TRY(hipEventRecord(q.ev_free, st));
+      if (xcall || n_pipes == 2) {
+        HIP_TRY(hipEventRecord(q.ev_free, st));
+        q.free_recorded = true;
+      }
+      s->chunk_seq++;
       done += nf;
     }
     HIP_TRY(hipGetLastError());

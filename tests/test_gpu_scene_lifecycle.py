@@ -84,3 +84,44 @@ def test_trim_destroys_the_parked_streams_and_scenes_still_work_afterwards(hip):
     fb = b.render(p)
     b.close()
     assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_calls_pipelined_across_the_call_boundary_keep_stream_order(hip):
+    """pipeline_calls (default): consecutive calls run on alternating internal streams and only their accumulation stays on the
+    caller's stream.  What the caller sees must be what stream order promises: a kernel queued BEHIND a call reads the
+    completed frame; calls into the same frame buffer land in call order (the running mean continues, frame0 > 0); two frame
+    buffers rendered alternately do not mix; and every frame equals the unpipelined one on the bits."""
+    from ezrt_amd import scene as S, scenes, trace
+    bs = scenes.bunny_scene(subdiv=1, hdr="shipped")
+    eye, cam = S.camera(0, 0, 4.0)
+    eye2, cam2 = S.camera(40, 10, 3.0)
+    st = torch.cuda.current_stream().cuda_stream
+    ref = bs.upload(hip)
+    ref.set_option("pipeline_calls", 0)
+    sc = bs.upload(hip)
+    W = H = 256
+
+    def P(e, c, spp, frame0=0):
+        return trace.make_params(W, H, e, c, 50, 4, spp=spp, frame0=frame0)
+
+    want_a = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    want_b = torch.zeros_like(want_a)
+    ref.render_device(P(eye, cam, 12), want_a.data_ptr(), st)
+    ref.render_device(P(eye2, cam2, 5), want_b.data_ptr(), st)
+    torch.cuda.synchronize()
+    a, b = torch.zeros_like(want_a), torch.zeros_like(want_a)
+    copies = []
+    for _ in range(3):   # no host synchronisation inside: everything below is queued back to back
+        sc.render_device(P(eye, cam, 4), a.data_ptr(), st)             # frames 0..3
+        copies.append(a.clone())                                       # a kernel queued behind the call
+        sc.render_device(P(eye2, cam2, 5), b.data_ptr(), st)           # another frame buffer in between
+        sc.render_device(P(eye, cam, 8, frame0=4), a.data_ptr(), st)   # frames 4..11 continue the running mean
+        copies.append(a.clone())
+    torch.cuda.synchronize()
+    part = torch.zeros_like(want_a)
+    ref.render_device(P(eye, cam, 4), part.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int32), want_a.view(torch.int32)) and torch.equal(b.view(torch.int32), want_b.view(torch.int32))
+    for k, c in enumerate(copies):
+        assert torch.equal(c.view(torch.int32), (part if k % 2 == 0 else want_a).view(torch.int32)), k
