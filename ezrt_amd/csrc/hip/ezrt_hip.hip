@@ -153,7 +153,8 @@ struct Tuning {
                            // ray per path; 2: the MIS integrators' two-ray queues too -- measured slower there)
   int pipeline_calls = 1;  // consecutive chunks -- of one call or of consecutive calls -- alternate between the two scratch sets and their own
                            // streams, so that a chunk's latency-bound late stages run under the next chunk's primary stage; only the
-                           // accumulation into the caller's frame buffer stays on the caller's stream, in order (ezrt_render_device)
+                           // accumulation into the caller's frame buffer stays on the caller's stream, in order (ezrt_render_device).
+                           // 1 (default): scenes of up to 64 MiB on the device; 2: always; 0: never
   int audit_via_queue = 0; // 1: ezrt_query_hits and ezrt_render_paths run through the TIMED kernels (traceq_kernel with
                            // the template, LDS layout, stealing and redo launch of a render call + the streaming shading
                            // stages) instead of the in-order audit kernels; 2 (query only): additionally treat the rays as
@@ -210,7 +211,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"stack_cap", &Tuning::stack_cap, 0, 64},
                               {"debug_stack_cap", &Tuning::debug_stack_cap, 0, 64},
                               {"bounce_scatter", &Tuning::bounce_scatter, 0, 2},
-                              {"pipeline_calls", &Tuning::pipeline_calls, 0, 1},
+                              {"pipeline_calls", &Tuning::pipeline_calls, 0, 2},
                               {"audit_via_queue", &Tuning::audit_via_queue, 0, 2}};
 Tuning tuning_from_env() {
   Tuning t;
@@ -2202,7 +2203,12 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
     // only after the accumulation that read its samples (ev_free).  What it buys: the small late stages of a chunk last as long as
     // their deepest rays (section 6 of DESIGN.md) and leave most of the chip idle; the next chunk's primary stage now runs under
     // them.  Two independent scenes on two streams showed the potential first: C2 +10-11 % aggregate, C4 +-0 (tools/exp_two_streams.py).
-    const bool xcall = !use_mega && n_pipes == 1 && s->tune.pipeline_calls && !s->tune.debug_stages;
+    // Measured (profiles/r4/pipeline_calls_ab.txt): C2 12.7 -> 14.4-14.6 Grays/s (+13-14 %), C4 +1.9 %; C3 -2.4 % and C5 -1.0 % --
+    // scenes of 57 and 112 MB of geometry whose stages are cache-bound and not small: two stages with different working sets
+    // thrash the 4 MB L2s more than the overlap buys.  So knob value 1 (default) pipelines scenes of up to 64 MiB on the device
+    // (ezrt_scene_stats[5]: C2 / C4 22 MB), 2 always, 0 never.
+    const bool xcall = !use_mega && n_pipes == 1 && !s->tune.debug_stages &&
+                       (s->tune.pipeline_calls == 2 || (s->tune.pipeline_calls == 1 && s->stats[5] <= ((int64_t)64 << 20)));
     const int n_scratch = xcall ? 2 : n_pipes;
     if (!use_mega) { // size the chunk's queues now: if they do not fit, halve the chunk (same results, more launches)
       const bool mis = p->integrator == EZRT_INTEGRATOR_P5_MIS || p->integrator == EZRT_INTEGRATOR_P5_MIS_ANISO;

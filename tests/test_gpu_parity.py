@@ -296,8 +296,8 @@ def test_schedule_knobs_never_change_results(hip, bunny_small):
                      {"anyhit": 1, "debug_stack_cap": 1}, {"anyhit": 1, "prune": 0},
                      {"lazy_dir": 0}, {"lazy_dir": 1, "debug_force_pending": 3}, {"refill_min_rel": 0}, {"refill_min_rel": 64},
                      {"refill_min_rel": 1, "refill_min": 1},
-                     {"pipeline_calls": 0}, {"pipeline_calls": 0, "chunk_log2": 12}, {"pipeline_calls": 1, "chunk_log2": 12},
-                     {"pipeline_calls": 1, "debug_oom_above": 30000}, {"pipeline_calls": 1, "debug_force_pending": 3, "redo_overlap": 1},
+                     {"pipeline_calls": 0}, {"pipeline_calls": 0, "chunk_log2": 12}, {"pipeline_calls": 2, "chunk_log2": 12},
+                     {"pipeline_calls": 2, "debug_oom_above": 30000}, {"pipeline_calls": 2, "debug_force_pending": 3, "redo_overlap": 1},
                      {"bounce_scatter": 0}, {"bounce_scatter": 2}, {"bounce_scatter": 2, "debug_force_pending": 3}, {"bounce_scatter": 2, "steal": 0},
                      {"bounce_scatter": 1, "pool_max": 8}, {"bounce_scatter": 2, "static_pct": 0}, {"bounce_scatter": 2, "chunk_log2": 12}):
             s2 = bunny_small.upload(hip)
