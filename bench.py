@@ -222,27 +222,31 @@ def time_config(name, hip, torch, dev, stream, env, spp_override=0, check=True, 
 
 def scaling_model(tag, sc, hip, torch, dev, stream, make_p, W, H, tile, shards=(2, 4, 8), reps=3):
     """What an N-GPU strong split of this frame would cost, measured on ONE GPU: shard r of N rendered alone (the tiles rank r
-    would own; median of `reps` calls), max over r = the critical path of the render phase; + the pack kernel, the payload
+    would own; median of `reps` bursts of 4 back-to-back calls), max over r = the critical path of the render phase; + the pack kernel, the payload
     over one xGMI link (each peer has its own link to rank 0), and the N - 1 un-permute kernels on rank 0.  RCCL's own
     launch / protocol latency is NOT measurable here and is left out (stated in the field)."""
     from ezrt_amd import tiles
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
 
-    def timed(fn, n):
+    def timed(fn, n, burst=1):
+        """median over n measurements of `burst` back-to-back calls (ms per call).  Render calls are measured in bursts of 4: the
+        steps of a timed window are queued back to back too, and consecutive calls overlap (pipeline_calls) -- a lone call
+        between two synchronisations would overstate what a shard costs in steady state."""
         fn()
         torch.cuda.synchronize()
         ts = []
         for _ in range(n):
             t0 = time.perf_counter()
-            fn()
+            for _ in range(burst):
+                fn()
             torch.cuda.synchronize()
-            ts.append((time.perf_counter() - t0) * 1e3)
+            ts.append((time.perf_counter() - t0) * 1e3 / burst)
         return statistics.median(ts)
 
-    t1 = timed(lambda: sc.render_device(make_p((0, 1)), acc.data_ptr(), stream), reps)
+    t1 = timed(lambda: sc.render_device(make_p((0, 1)), acc.data_ptr(), stream), reps, 4)
     out = {"workload": tag, "one_gpu_ms": round(t1, 4), "shards": {}}
     for n in shards:
-        per = [timed(lambda r=r: sc.render_device(make_p((r, n)), acc.data_ptr(), stream), reps) for r in range(n)]
+        per = [timed(lambda r=r: sc.render_device(make_p((r, n)), acc.data_ptr(), stream), reps, 4) for r in range(n)]
         plan = tiles.TilePlan(W, H, tile, tile, n)
         nfl = plan.per_rank * tile * tile * 4
         packed = torch.zeros(nfl, dtype=torch.float32, device=dev)
