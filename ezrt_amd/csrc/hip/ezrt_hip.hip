@@ -154,7 +154,7 @@ struct Tuning {
   int pipeline_calls = 1;  // consecutive chunks -- of one call or of consecutive calls -- alternate between the two scratch sets and their own
                            // streams, so that a chunk's latency-bound late stages run under the next chunk's primary stage; only the
                            // accumulation into the caller's frame buffer stays on the caller's stream, in order (ezrt_render_device).
-                           // 1 (default): scenes of up to 64 MiB on the device; 2: always; 0: never
+                           // 1 (default): scenes of up to 64 MiB on the device traced with >= 3 bounces; 2: always; 0: never
   int audit_via_queue = 0; // 1: ezrt_query_hits and ezrt_render_paths run through the TIMED kernels (traceq_kernel with
                            // the template, LDS layout, stealing and redo launch of a render call + the streaming shading
                            // stages) instead of the in-order audit kernels; 2 (query only): additionally treat the rays as
@@ -2205,10 +2205,14 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
     // them.  Two independent scenes on two streams showed the potential first: C2 +10-11 % aggregate, C4 +-0 (tools/exp_two_streams.py).
     // Measured (profiles/r4/pipeline_calls_ab.txt): C2 12.7 -> 14.4-14.6 Grays/s (+13-14 %), C4 +1.9 %; C3 -2.4 % and C5 -1.0 % --
     // scenes of 57 and 112 MB of geometry whose stages are cache-bound and not small: two stages with different working sets
-    // thrash the 4 MB L2s more than the overlap buys.  So knob value 1 (default) pipelines scenes of up to 64 MiB on the device
-    // (ezrt_scene_stats[5]: C2 / C4 22 MB), 2 always, 0 never.
+    // thrash the 4 MB L2s more than the overlap buys -- and C4 at its 256 spp (four chunks per call) -5 %: its three stages are all
+    // large and throughput-bound (2 bounces, most paths alive to the end), there is no latency-bound tail to hide, and a
+    // persistent trace launch that holds every wave slot only delays the other chunk's shading kernels.  So knob value 1
+    // (default) pipelines when BOTH hold: the scene is at most 64 MiB on the device (ezrt_scene_stats[5]: C2 / C4 22 MB) and
+    // the call traces at least three bounces (its chunks then end in small stages: every bounce loses paths); 2 always, 0 never.
     const bool xcall = !use_mega && n_pipes == 1 && !s->tune.debug_stages &&
-                       (s->tune.pipeline_calls == 2 || (s->tune.pipeline_calls == 1 && s->stats[5] <= ((int64_t)64 << 20)));
+                       (s->tune.pipeline_calls == 2 ||
+                        (s->tune.pipeline_calls == 1 && s->stats[5] <= ((int64_t)64 << 20) && p->max_bounce >= 3));
     const int n_scratch = xcall ? 2 : n_pipes;
     if (!use_mega) { // size the chunk's queues now: if they do not fit, halve the chunk (same results, more launches)
       const bool mis = p->integrator == EZRT_INTEGRATOR_P5_MIS || p->integrator == EZRT_INTEGRATOR_P5_MIS_ANISO;
