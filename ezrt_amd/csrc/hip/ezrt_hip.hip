@@ -2280,10 +2280,9 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
       b.samples = q.samples.p;
       b.accum = reinterpret_cast<float4*>(accum_dev);
       hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, st, b);
-      if (xcall || n_pipes == 2) {
-        HIP_TRY(hipEventRecord(q.ev_free, st));
-        q.free_recorded = true;
-      }
+      // (recorded in every mode: a later pipelined chunk on this scratch set's own stream must wait for THIS use of it too)
+      HIP_TRY(hipEventRecord(q.ev_free, st));
+      q.free_recorded = true;
       s->chunk_seq++;
       done += nf;
     }
@@ -2354,6 +2353,7 @@ int ezrt_frame_write(float* frame_dev, int width, int height, const float* rgba_
 }
 
 int ezrt_render_paths(EzrtScene* s, const EzrtRenderParams* p, int32_t* tri_id, float* t_hit, float* colour) {
+  if (s) (void)hipDeviceSynchronize(); // (a synchronous audit call: pipelined chunks of earlier render calls may still own the scratch it reuses)
   if (!s || !tri_id || !t_hit) return fail(EZRT_ERR_INVALID, "NULL argument");
   int rc = validate_params(s, p);
   if (rc) return rc;
@@ -2420,6 +2420,7 @@ int ezrt_query_hits(EzrtScene* s, const float* rays, int n_rays, int32_t* tri_id
   HIP_TRY(hipMemcpy(dr.p, rays, (size_t)n_rays * 6 * sizeof(float), hipMemcpyHostToDevice));
   if (s->tune.audit_via_queue) {
     // the rays as ONE stage of a render call: same kernel template, LDS layout, pools, stealing, redo launch
+    HIP_TRY(hipDeviceSynchronize()); // (pipelined chunks of earlier render calls may still own the scratch this reuses)
     int rc = ensure_num_cus(s);
     if (rc) return rc;
     Pipe& pp = s->pipe[0];
