@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/profile_configs.sh [CFG ...]: rocprofv3 evidence for BASELINE configs[2..4] at their stated spp (VERDICT r3 #1c) -- one
-# --kernel-trace --stats run and four --pmc passes (each its own run, --kernel-trace only) of tools/config_one.py per config;
+# --kernel-trace --stats run and four --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a pass) (each its own run, --kernel-trace only) of tools/config_one.py per config;
 # tools/summarize_config_profile.py turns them into profiles/r4/<cfg>_kernel_stats.csv and <cfg>_pmc_summary.json.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 CFGS=${@:-C3 C4 C5}
@@ -15,10 +15,9 @@ for c in $CFGS; do
   timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- $CMD > $O/stats.log 2>&1
   CMD="python $R/tools/config_one.py $c ${SPP_PMC[$c]}"
   i=0
-  for PMC in "FETCH_SIZE WRITE_SIZE" \
+  for PMC in "FETCH_SIZE" "WRITE_SIZE" \
              "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
-             "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT" \
-             "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
+             "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
     i=$((i+1))
     timeout 150 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $O/pmc$i -o p -- $CMD > $O/pmc$i.log 2>&1 || echo "$c: pmc pass $i failed: $PMC"
   done

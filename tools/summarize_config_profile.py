@@ -57,18 +57,18 @@ def main():
         c = {n: sum(v) / len(v) for n, v in agg.get(k, {}).items()}
         e = {"calls": calls, "avg_us": round(avg_ns / 1e3, 2), "total_ms": round(tot_ns / 1e6, 3), "share_of_gpu_time": round(tot_ns / total, 4) if total else None}
         pd = pdur.get(k, {})
-        if "SQ_INSTS_VALU" in c and pd.get("SQ_INSTS_VALU", 0) > 0:
+        if c.get("SQ_INSTS_VALU", 0) > 0 and pd.get("SQ_INSTS_VALU", 0) > 0:
             e["avg_us_in_counter_pass"] = round(pd["SQ_INSTS_VALU"] / 1e3, 2)
             rate = c["SQ_INSTS_VALU"] / (pd["SQ_INSTS_VALU"] * 1e-9) / 1e12
             e.update({"valu_wave_instr_per_dispatch": int(c["SQ_INSTS_VALU"]), "issue_rate_T": round(rate, 4),
                       "issue_frac_of_measured_peak_1.086": round(rate / 1.086, 4), "issue_frac_of_nominal_peak_1.229": round(rate / 1.2288, 4)})
-            if "SQ_THREAD_CYCLES_VALU" in c:
+            if "SQ_THREAD_CYCLES_VALU" in c and c["SQ_INSTS_VALU"] > 0:
                 e["lane_fill"] = round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"]), 4)
         if c.get("SQ_WAVE_CYCLES"):
             e["wave_cycles_waiting"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4)
-        if "FETCH_SIZE" in c and pd.get("FETCH_SIZE", 0) > 0:
-            hbm = (2.0 * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024.0
-            sec = pd["FETCH_SIZE"] * 1e-9
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c and pd.get("FETCH_SIZE", 0) > 0:
+            hbm = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+            sec = 0.5 * (pd["FETCH_SIZE"] + pd.get("WRITE_SIZE", pd["FETCH_SIZE"])) * 1e-9   # (the two counters come from two passes)
             e.update({"hbm_bytes_per_dispatch_in_counter_pass": int(hbm), "hbm_GBs": round(hbm / sec / 1e9, 1), "hbm_frac_of_8TBs": round(hbm / sec / 8e12, 4)})
         if "TCP_TCC_READ_REQ_sum" in c:
             e["l1_to_l2_read_requests"] = int(c["TCP_TCC_READ_REQ_sum"])
