@@ -39,8 +39,30 @@ EZD f3 operator/(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
 EZD f3 operator-(f3 a) { return mk(-a.x, -a.y, -a.z); }
 EZD float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 EZD f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+// 1.0f / x, correctly rounded -- the same bits as the division the compiler emits for `1.0f / x` (IEEE binary32, round to nearest
+// even: what gcc produces for the oracle), in 4 VALU instructions instead of the 10 + hazard nops of the general division macro
+// (v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup): v_rcp_f32 is within 1 ulp, one Newton step on the residual computed with
+// a fused multiply-add (the rounding of THIS primitive's result is what the contract fixes, not how it is reached) lands on the
+// correctly rounded quotient for every |x| in [2^-120, 2^120]; everything else -- zeros, denormals, huge values whose reciprocal is
+// denormal, infinities, NaNs -- takes the compiler's division.  Not a claim: tests/test_gpu_parity.py runs ALL 2^32 bit patterns
+// through both on the device (ezrt_debug_math op 18) and requires zero mismatches.  Rays per refill: three of these (1 / d) + the
+// normalisation of a generated primary direction; the shading kernels' normalisations.
+#ifndef EZRT_FAST_RCP
+#define EZRT_FAST_RCP 1 // (0: A/B builds, tools/build_variant.sh)
+#endif
+EZD float ez_rcp(float x) {
+  if (!EZRT_FAST_RCP) return 1.0f / x;
+  const float ax = __builtin_fabsf(x);
+  if (ax >= 7.5231638e-37f && ax <= 1.329228e36f) { // [2^-120, 2^120]
+    float r = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r, 1.0f);
+    r = __builtin_fmaf(r, e, r);
+    return r;
+  }
+  return 1.0f / x;
+}
 EZD f3 normalize(f3 a) {
-  float inv = 1.0f / __builtin_sqrtf(dot(a, a));
+  float inv = ez_rcp(__builtin_sqrtf(dot(a, a)));
   return a * inv;
 }
 EZD f3 mix3(f3 a, f3 b, float t) { return mk(ez_mix(a.x, b.x, t), ez_mix(a.y, b.y, t), ez_mix(a.z, b.z, t)); }
@@ -279,7 +301,7 @@ EZD void hit_bvh(const DevScene& sc, f3 S, f3 d, int* __restrict__ stack, int32_
   ctr.rays++;
   best_tri = -1;
   best_t = INF;
-  f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  f3 inv = mk(ez_rcp(d.x), ez_rcp(d.y), ez_rcp(d.z));
   int sp = 0;
   uint32_t ref = sc.root_ref;
   for (;;) {

@@ -2629,8 +2629,24 @@ int ezrt_scene_stats(EzrtScene* s, int64_t out[6]) {
 }
 
 int ezrt_debug_math(int op, const float* a, const float* b, int n, float* out) {
-  if (!a || !out || n < 0 || op < 0 || op > 17) return fail(EZRT_ERR_INVALID, "bad argument");
+  if (!a || !out || n < 0 || op < 0 || op > 18) return fail(EZRT_ERR_INVALID, "bad argument");
   if (n == 0) return 0;
+  if (op == 18) { // exhaustive audit of the device's correctly rounded reciprocal (ez_rcp): out[0] = mismatches over all 2^32 inputs, out[1] = bits of the first
+    if (n < 2) return fail(EZRT_ERR_INVALID, "op 18 writes two values");
+    DevBuf<unsigned long long> res;
+    HIP_TRY(res.ensure(2));
+    const unsigned long long init[2] = {0ull, ~0ull};
+    HIP_TRY(hipMemcpy(res.p, init, sizeof init, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rcp_audit_kernel, dim3(4096), dim3(256), 0, nullptr, res.p);
+    HIP_TRY(hipGetLastError());
+    unsigned long long got[2];
+    HIP_TRY(hipMemcpy(got, res.p, sizeof got, hipMemcpyDeviceToHost));
+    out[0] = (float)(got[0] > 16777216ull ? 16777216ull : got[0]);
+    const uint32_t fb = got[0] ? (uint32_t)got[1] : 0u;
+    memcpy(&out[1], &fb, 4);
+    for (int i = 2; i < n; i++) out[i] = 0.0f;
+    return 0;
+  }
   if (op == 17) { // floor(bits(a[i]) / bits(b[0])) through the kernels' FastDiv
     uint32_t d = 0;
     if (!b) return fail(EZRT_ERR_INVALID, "bad argument");

@@ -108,6 +108,9 @@ EZD float4 primary_dir(const EzrtRenderParams& p, const int2* blocks, const Fast
   const uint32_t ix = (uint32_t)x, iy = (uint32_t)y;
   uint32_t seed = (ix * 1973u + iy * 9277u + frame * 26699u) | 1u;
   const float W = (float)p.width, H = (float)p.height;
+  // (x / W for a power-of-two W IS x * (1 / W) on the bits, and every BASELINE frame is one: the four divisions below as
+  // multiplications behind a uniform branch were built and measured in round 4 -- C2 -3.3 %: four more launch-invariant values
+  // in a kernel at its SGPR limit became three more VGPR spills in the refill block; profiles/r4/rcp_pow2_ab.txt)
   float pixx = ((float)ix + 0.5f) / W * 2.0f - 1.0f;
   float pixy = ((float)iy + 0.5f) / H * 2.0f - 1.0f;
   float aax = (rnd(seed) - 0.5f) / W;
@@ -481,10 +484,31 @@ __global__ void isect_kernel(int op, const float* a, const float* b, int n, floa
     return;
   }
   const float* q = b + 6 * (size_t)i;
-  f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  f3 inv = mk(ez_rcp(d.x), ez_rcp(d.y), ez_rcp(d.z));
   f3 AA = mk(q[0], q[1], q[2]), BB = mk(q[3], q[4], q[5]);
   if (op == 10) out[i] = hit_aabb(S, inv, AA, BB);
   else out[i] = ray_is_tame(S, inv) ? hit_aabb_tame(S, inv, AA, BB) : __uint_as_float(0x7fc00000u);
+}
+
+// ezrt_debug_math op 18: ez_rcp(x) against the compiler's `1.0f / x` for ALL 2^32 bit patterns of x (a NaN equals a NaN).
+// res[0] = mismatches, res[1] = the smallest mismatching pattern.
+__global__ void rcp_audit_kernel(unsigned long long* res) {
+  unsigned long long bad = 0ull, first = ~0ull;
+  for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < (1ull << 32); k += (unsigned long long)gridDim.x * blockDim.x) {
+    const float x = __uint_as_float((uint32_t)k);
+    float want;
+    asm volatile("" : "=v"(want) : "0"(1.0f / x)); // (keep the two expressions apart)
+    const float got = ez_rcp(x);
+    const bool same = __float_as_uint(got) == __float_as_uint(want) || (got != got && want != want);
+    if (!same) {
+      bad++;
+      if (k < first) first = k;
+    }
+  }
+  if (bad) {
+    atomicAdd(&res[0], bad);
+    atomicMin(&res[1], first);
+  }
 }
 
 } // namespace ezd

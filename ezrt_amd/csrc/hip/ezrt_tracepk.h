@@ -49,7 +49,7 @@ __global__ __launch_bounds__(BLOCK) void tracepk_kernel(TracePkArgs a) {
   const float4 ro4 = make_float4(a.origin[0], a.origin[1], a.origin[2], 0.0f);
   const bool valid = rd4.w != 0.0f;
   const f3 S = mk(ro4.x, ro4.y, ro4.z), d = mk(rd4.x, rd4.y, rd4.z);
-  const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  const f3 inv = mk(ez_rcp(d.x), ez_rcp(d.y), ez_rcp(d.z));
   const bool any_wild = ballot(valid && !ray_is_tame(S, inv)) != 0ull;
   float best_t = INF;
   int32_t best_tri = -1;

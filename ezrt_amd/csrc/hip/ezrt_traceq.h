@@ -213,7 +213,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
           slot = adopted;
           S = mk(nx_o.x, nx_o.y, nx_o.z);
           d = mk(nx_d.x, nx_d.y, nx_d.z);
-          inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+          inv = mk(ez_rcp(d.x), ez_rcp(d.y), ez_rcp(d.z));
           wild = !ray_is_tame(S, inv);
           best_t = INF;
           best_tri = -1;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void traceq_kernel(TraceQArgs a) {
             slot = vslot;
             S = mk(vsx, vsy, vsz);
             d = mk(vdx, vdy, vdz);
-            inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            inv = mk(ez_rcp(d.x), ez_rcp(d.y), ez_rcp(d.z));
             wild = vwild != 0;
             best_t = INF;
             best_tri = -1;

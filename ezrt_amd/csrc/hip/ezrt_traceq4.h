@@ -362,7 +362,7 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
           tie = false;
           if (hook.shade(slot, S, d, best_tri, best_t, bl)) { // the path goes on: S, d = its next ray
             n_counted += a.count_rays;
-            inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            inv = mk(ez_rcp(d.x), ez_rcp(d.y), ez_rcp(d.z));
             best_t = INF;
             best_tri = -1;
             sp = 0;
@@ -388,7 +388,7 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
           // it, no prefetched origin, none of its shuffles in the leaf and steal phases (7 VGPRs less at a budget of 80)
           S = REL ? mk(a.origin[0], a.origin[1], a.origin[2]) : mk(nx_o.x, nx_o.y, nx_o.z);
           d = mk(nx_d.x, nx_d.y, nx_d.z);
-          inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+          inv = mk(ez_rcp(d.x), ez_rcp(d.y), ez_rcp(d.z));
           best_t = INF;
           best_tri = -1;
           sp = 0;
@@ -496,7 +496,7 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
             slot = vslot;
             S = mk(vsx, vsy, vsz);
             d = mk(vdx, vdy, vdz);
-            inv = mk(1.0f / vdx, 1.0f / vdy, 1.0f / vdz);
+            inv = mk(ez_rcp(vdx), ez_rcp(vdy), ez_rcp(vdz));
             best_t = INF;
             best_tri = -1;
             sp = 0;

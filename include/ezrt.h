@@ -122,7 +122,12 @@ int ezrt_render(EzrtScene* s, const EzrtRenderParams* p, float* accum_rgba);
  * ONE STREAM PER SCENE: the queues, counters and block list of a render call are
  * scratch owned by the EzrtScene, so calls on one scene must be ordered -- same
  * stream, or the caller synchronises between streams.  Scenes are independent:
- * concurrent streams (or devices, include/ezrt_mgpu.h) take one scene each. */
+ * concurrent streams (or devices, include/ezrt_mgpu.h) take one scene each.
+ * WHAT `stream` ORDERS: every access to accum_rgba_dev (the accumulation of the call's samples) is enqueued on `stream`, in
+ * call order, behind whatever the caller queued before; work queued behind the call finds the frame complete, and a host
+ * that synchronises `stream` has synchronised the call.  The tracing itself touches only the scene's own scratch and may run
+ * on streams of the library's own, overlapping the previous call's tail (option "pipeline_calls") -- which no
+ * stream-ordered caller can observe. */
 int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_rgba_dev, void* stream);
 
 /* A device-resident lastFrame for hosts without their own device allocator (the GL texture of P5/main.cpp:926-929:
@@ -193,7 +198,9 @@ int ezrt_scene_prune_info(EzrtScene* s, double out[8]);
  * 9 floats); ops 13-16 audit integrator 52's sampler in the frame N = (0,0,1) (b = n x (roughness, anisotropic,
  * metallic, clearcoat, clearcoatGloss, -)): 13: a = n x (V, L) -> its pdf; 14/15/16: a = n x (xi1, xi2, xi3, V)
  * -> x / y / z of the sampled direction.  Op 17: out bits = floor(bits(a[i]) / bits(b[0])), 32-bit unsigned, computed
- * the way the kernels divide by launch-invariant counts (exact for every operand). */
+ * the way the kernels divide by launch-invariant counts (exact for every operand).  Op 18 (n >= 2; a is ignored): the
+ * implementation's reciprocal 1.0f / x checked against IEEE division for ALL 2^32 bit patterns of x on its compute device
+ * -- out[0] = number of mismatches (a NaN equals a NaN), out bits [1] = the first mismatching pattern; the oracle divides, so 0. */
 int ezrt_debug_math(int op, const float* a, const float* b, int n, float* out);
 
 const char* ezrt_last_error(void);

@@ -268,6 +268,21 @@ def test_exact_distance_ties_follow_the_reference_visit_order(hip, oracle, bunny
     assert np.array_equal(tg, to) and (tg[..., 0] >= 0).mean() > 0.02
 
 
+def test_fast_reciprocal_is_the_ieee_division_for_every_float(hip):
+    """ez_rcp (ezrt_device.h: v_rcp_f32 + one fused Newton step inside [2^-120, 2^120], the compiler's division outside) must be
+    `1.0f / x` on the bits: ALL 2^32 patterns are compared on the device (ezrt_debug_math op 18)."""
+    out = hip.debug_math(18, np.zeros(2, np.float32))
+    assert out[0] == 0.0, "mismatches: %g, first input bits 0x%08x" % (out[0], int(out[1:2].view(np.uint32)[0]))
+
+
+def test_frame_sizes_that_are_not_powers_of_two(hip, oracle, bunny_small):
+    """Frame sizes of every kind through the in-launch ray generation (primary_dir): powers of two and not, W != H."""
+    eye, cam = S.camera(20, 10, 3.5)
+    for w, h in ((96, 80), (128, 80), (100, 64), (64, 64)):
+        p = trace.make_params(w, h, eye, cam, 50, 3, spp=2)
+        assert np.array_equal(_bits(bunny_small.upload(hip).render(p)), _bits(bunny_small.upload(oracle).render(p))), (w, h)
+
+
 def test_schedule_knobs_never_change_results(hip, bunny_small):
     """ezrt_set_option only reschedules the same arithmetic: every combination is bit-identical."""
     sg = bunny_small.upload(hip)
