@@ -7,6 +7,10 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# (EZRT_PIPELINE_CALLS=0: the kernels are profiled running ALONE -- consecutive steps otherwise overlap (DESIGN.md 5 "pipeline_calls") and a
+# kernel's duration in the trace would include waiting for wave slots held by the other chunk's launches; bench.py's own trace_ms_per_step
+# comes from a sequential pass too, and the counter passes serialise every dispatch anyway)
+export EZRT_PIPELINE_CALLS=0
 BENCH="python $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --extras 0 --configs none --model 0 $@"
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $BENCH > $OUT/stats.log 2>&1
 i=0
