@@ -154,7 +154,11 @@ struct Tuning {
   int pipeline_calls = 1;  // consecutive chunks -- of one call or of consecutive calls -- alternate between the two scratch sets and their own
                            // streams, so that a chunk's latency-bound late stages run under the next chunk's primary stage; only the
                            // accumulation into the caller's frame buffer stays on the caller's stream, in order (ezrt_render_device).
-                           // 1 (default): scenes of up to 64 MiB on the device traced with >= 3 bounces; 2: always; 0: never
+                           // 1 (default; 2 is accepted as the same): every scene; 0: never
+  int static_pct_pipelined = 0; // static_pct of the trace launches of a pipelined chunk: its workgroups become resident as the other chunk's
+                           // launches free wave slots, and a pool dealt statically to a workgroup that arrives late is the launch's tail.
+                           // With the queues all dynamic pipelining gains on every config (C3 +3.0 %, C4 +2.6 %, C5 +1.8 %, C2 +13 %); with
+                           // the unpipelined optimum of 50 it lost 1-5 % on C3 / C4 / C5 (profiles/r4/pipeline_calls_ab.txt)
   int audit_via_queue = 0; // 1: ezrt_query_hits and ezrt_render_paths run through the TIMED kernels (traceq_kernel with
                            // the template, LDS layout, stealing and redo launch of a render call + the streaming shading
                            // stages) instead of the in-order audit kernels; 2 (query only): additionally treat the rays as
@@ -212,6 +216,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"debug_stack_cap", &Tuning::debug_stack_cap, 0, 64},
                               {"bounce_scatter", &Tuning::bounce_scatter, 0, 2},
                               {"pipeline_calls", &Tuning::pipeline_calls, 0, 2},
+                              {"static_pct_pipelined", &Tuning::static_pct_pipelined, 0, 95},
                               {"audit_via_queue", &Tuning::audit_via_queue, 0, 2}};
 Tuning tuning_from_env() {
   Tuning t;
@@ -304,6 +309,7 @@ struct EzrtScene {
   Pipe pipe[2];
   int num_cus = 0;
   uint32_t chunk_seq = 0;     // chunks rendered so far (pipeline_calls: chunk i uses scratch set i & 1)
+  bool chunk_pipelined = false; // the chunk being enqueued runs on a scratch set's own stream (set by ezrt_render_device)
   int n_inner = 0;
   Tuning tune = tuning_from_env();
   // timing
@@ -892,7 +898,8 @@ void launch_traceq4_cfg(EzrtScene* s, const TraceCfg& c4, const TraceQArgs& t, c
 void fill_trace_knobs(const EzrtScene* s, const TraceCfg& c, TraceQArgs& t) {
   const Tuning& tu = s->tune;
   t.leaf_threshold = tu.leaf_threshold < 1 ? 1 : (tu.leaf_threshold > 64 ? 64 : tu.leaf_threshold);
-  t.static_pct = (uint32_t)(tu.static_pct < 0 ? 0 : (tu.static_pct > 95 ? 95 : tu.static_pct));
+  const int spct = s->chunk_pipelined ? tu.static_pct_pipelined : tu.static_pct;
+  t.static_pct = (uint32_t)(spct < 0 ? 0 : (spct > 95 ? 95 : spct));
   t.refill_min = (uint32_t)(tu.refill_min < 1 ? 1 : (tu.refill_min > 64 ? 64 : tu.refill_min));
   t.pool_div = (uint32_t)(tu.pool_div < 1 ? 1 : tu.pool_div);
   t.pool_max = (uint32_t)(tu.pool_max < (int)TRACE_POOL_MIN ? (int)TRACE_POOL_MIN : (tu.pool_max > 4096 ? 4096 : tu.pool_max));
@@ -2203,16 +2210,12 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
     // only after the accumulation that read its samples (ev_free).  What it buys: the small late stages of a chunk last as long as
     // their deepest rays (section 6 of DESIGN.md) and leave most of the chip idle; the next chunk's primary stage now runs under
     // them.  Two independent scenes on two streams showed the potential first: C2 +10-11 % aggregate, C4 +-0 (tools/exp_two_streams.py).
-    // Measured (profiles/r4/pipeline_calls_ab.txt): C2 12.7 -> 14.4-14.6 Grays/s (+13-14 %), C4 +1.9 %; C3 -2.4 % and C5 -1.0 % --
-    // scenes of 57 and 112 MB of geometry whose stages are cache-bound and not small: two stages with different working sets
-    // thrash the 4 MB L2s more than the overlap buys -- and C4 at its 256 spp (four chunks per call) -5 %: its three stages are all
-    // large and throughput-bound (2 bounces, most paths alive to the end), there is no latency-bound tail to hide, and a
-    // persistent trace launch that holds every wave slot only delays the other chunk's shading kernels.  So knob value 1
-    // (default) pipelines when BOTH hold: the scene is at most 64 MiB on the device (ezrt_scene_stats[5]: C2 / C4 22 MB) and
-    // the call traces at least three bounces (its chunks then end in small stages: every bounce loses paths); 2 always, 0 never.
-    const bool xcall = !use_mega && n_pipes == 1 && !s->tune.debug_stages &&
-                       (s->tune.pipeline_calls == 2 ||
-                        (s->tune.pipeline_calls == 1 && s->stats[5] <= ((int64_t)64 << 20) && p->max_bounce >= 3));
+    // Measured (profiles/r4/pipeline_calls_ab.txt): C2 12.7 -> 14.4-14.6 Grays/s (+13-14 %).  With the trace queues dealt half
+    // statically (the unpipelined optimum) C3 / C5 / C4-at-256-spp LOST 2.4 / 1.0 / 5 %: a pipelined chunk's persistent trace
+    // workgroups become resident only as the other chunk's launches free wave slots, and the pools dealt statically to a
+    // workgroup that arrives late are the launch's tail.  With all-dynamic queues for pipelined chunks (static_pct_pipelined
+    // = 0) every config gains: C3 +3.0 %, C4 +2.6 %, C5 +1.8 %, C2 unchanged at +13 %.  So every scene is pipelined.
+    const bool xcall = !use_mega && n_pipes == 1 && !s->tune.debug_stages && s->tune.pipeline_calls != 0;
     const int n_scratch = xcall ? 2 : n_pipes;
     if (!use_mega) { // size the chunk's queues now: if they do not fit, halve the chunk (same results, more launches)
       const bool mis = p->integrator == EZRT_INTEGRATOR_P5_MIS || p->integrator == EZRT_INTEGRATOR_P5_MIS_ANISO;
@@ -2264,7 +2267,9 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
         }
         s->n_trace_launches++;
       } else {
+        s->chunk_pipelined = xcall;
         rc = wavefront_chunk(s, q, p, nb, p->frame0 + done, nf, qs);
+        s->chunk_pipelined = false;
         if (rc) return rc;
       }
       if (xcall || n_pipes == 2) { // the running mean is applied in frame order, on the caller's stream

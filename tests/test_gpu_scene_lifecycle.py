@@ -125,15 +125,17 @@ def test_calls_pipelined_across_the_call_boundary_keep_stream_order(hip):
     assert torch.equal(a.view(torch.int32), want_a.view(torch.int32)) and torch.equal(b.view(torch.int32), want_b.view(torch.int32))
     for k, c in enumerate(copies):
         assert torch.equal(c.view(torch.int32), (part if k % 2 == 0 else want_a).view(torch.int32)), k
-    # pipelined calls (>= 3 bounces on a small scene) and plain ones (2 bounces: the default rule leaves them on the caller's
-    # stream) share the two scratch sets: queued back to back in every order they must not step on each other
+    # calls of different integrators / bounce counts (other kernels, other queue layouts) and plain, unpipelined calls (knob 0) share the
+    # two scratch sets: queued back to back in every order they must not step on each other
     want2 = torch.zeros_like(want_a)
     ref.render_device(trace.make_params(W, H, eye, cam, 51 if bs.cache is not None else 50, 2, spp=6), want2.data_ptr(), st)
     torch.cuda.synchronize()
     c2 = torch.zeros_like(want_a)
-    for _ in range(4):
+    for k in range(4):
         sc.render_device(P(eye, cam, 12), a.data_ptr(), st)
+        sc.set_option("pipeline_calls", k & 1)        # (takes effect at the next call: plain and pipelined chunks alternate)
         sc.render_device(trace.make_params(W, H, eye, cam, 51 if bs.cache is not None else 50, 2, spp=6), c2.data_ptr(), st)
+        sc.set_option("pipeline_calls", 1)
         sc.render_device(P(eye2, cam2, 5), b.data_ptr(), st)
         sc.render_device(P(eye2, cam2, 5), b.data_ptr(), st)
     torch.cuda.synchronize()
