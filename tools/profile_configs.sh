@@ -9,6 +9,9 @@ declare -A SPP=([C2]=64 [C3]=128 [C4]=256 [C5]=512)
 # are the same; the kernel-trace statistics above them are taken at the full BASELINE spp)
 declare -A SPP_PMC=([C2]=64 [C3]=32 [C4]=32 [C5]=8)
 cd /tmp && export TMPDIR=/tmp
+# (as tools/profile.sh: the kernels are profiled running ALONE; consecutive chunks otherwise overlap -- pipeline_calls -- and a kernel's
+# duration in the trace would include its wait for wave slots held by the other chunk's launches)
+export EZRT_PIPELINE_CALLS=0
 for c in $CFGS; do
   O=$R/gpurun_out/profcfg_$c; mkdir -p $O
   CMD="python $R/tools/config_one.py $c ${SPP[$c]}"

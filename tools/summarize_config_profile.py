@@ -75,7 +75,7 @@ def main():
             e["l1_accesses"] = int(c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0))
         kernels[k] = e
     trace_share = sum(v["share_of_gpu_time"] or 0 for k, v in kernels.items() if k.startswith("traceq"))
-    out = {"config": cfg, "command": "tools/config_one.py %s at the BASELINE spp (tools/profile_configs.sh)" % cfg, "source_sha": gpu_source_hash(),
+    out = {"config": cfg, "command": "EZRT_PIPELINE_CALLS=0 tools/config_one.py %s at the BASELINE spp (tools/profile_configs.sh): chunks NOT overlapped, every kernel measured alone" % cfg, "source_sha": gpu_source_hash(),
            "note": "kernel times and shares: rocprofv3 --kernel-trace --stats of the config at its BASELINE spp; counters: separate --pmc passes at one "
                    "chunk's worth of frames (same kernels, per-dispatch work smaller by the spp ratio for the per-chunk stages) -- the issue rate of a "
                    "kernel is its counters' VALU instructions / its average duration IN THE SAME pass",
