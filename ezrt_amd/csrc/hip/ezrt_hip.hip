@@ -657,11 +657,17 @@ int ensure_events(EzrtScene* s) {
     HIP_TRY(hipEventCreate(&s->ev_trace[i][1]));
   }
   s->n_trace_events_created = 64;
+  {
+    // (the device's shared pair: ezrt_streams.h says why the two streams the chunks alternate between are not the scene's own)
+    hipStream_t pair[2];
+    int dev = 0;
+    HIP_TRY(ezh::stream_shared_pair(pair, &dev));
+    s->pipe[0].stream = pair[0];
+    s->pipe[1].stream = pair[1];
+    s->pipe[0].stream_device = s->pipe[1].stream_device = dev;
+  }
   for (Pipe& q : s->pipe) {
-    // (from the process-wide pool: ezrt_streams.h says why the library never destroys a stream)
-    HIP_TRY(ezh::stream_acquire(false, &q.stream, &q.stream_device));
-    // the redo launches are a handful of rays on the critical path of the stage's second shading pass: highest priority
-    HIP_TRY(ezh::stream_acquire(true, &q.side, &q.stream_device));
+    // (the side stream of the redo launches -- knob redo_overlap, off by default -- is taken from the pool when first needed)
     HIP_TRY(hipEventCreateWithFlags(&q.ev_main, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&q.ev_redo, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&q.ev_done, hipEventDisableTiming));
@@ -1314,6 +1320,8 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
         r.wave_log = nullptr;
         r.force_pending = 0u;
         if (overlap_redo) {
+          // the redo launches are a handful of rays on the critical path of the stage's second shading pass: highest priority
+          if (!pp.side) HIP_TRY(ezh::stream_acquire(true, &pp.side, &pp.stream_device));
           HIP_TRY(hipEventRecord(pp.ev_main, st));
           HIP_TRY(hipStreamWaitEvent(pp.side, pp.ev_main, 0));
           launch_traceq_cfg(s, cfg, r, true, pp.side);
@@ -2083,8 +2091,7 @@ void ezrt_scene_destroy(EzrtScene* s) {
     (void)hipEventDestroy(s->ev_begin);
     (void)hipEventDestroy(s->ev_end);
     for (Pipe& q : s->pipe) {
-      ezh::stream_park(q.stream, false, q.stream_device);
-      ezh::stream_park(q.side, true, q.stream_device);
+      ezh::stream_park(q.side, true, q.stream_device); // (q.stream is the device's shared pair: released below, not parked)
       if (q.ev_main) (void)hipEventDestroy(q.ev_main);
       if (q.ev_redo) (void)hipEventDestroy(q.ev_redo);
       if (q.ev_done) (void)hipEventDestroy(q.ev_done);
@@ -2094,6 +2101,7 @@ void ezrt_scene_destroy(EzrtScene* s) {
       (void)hipEventDestroy(s->ev_trace[i][0]);
       (void)hipEventDestroy(s->ev_trace[i][1]);
     }
+    if (s->pipe[0].stream) ezh::stream_shared_release(s->pipe[0].stream_device);
   }
   delete s;
 }

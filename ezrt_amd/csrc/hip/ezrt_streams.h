@@ -44,6 +44,57 @@ inline hipError_t stream_acquire(bool high_priority, hipStream_t* out, int* devi
   return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio_hi);
 }
 
+// The two streams the chunks of a render call alternate between (ezrt_render_device, "pipeline_calls") are ONE PAIR PER DEVICE,
+// shared by every scene of the process, created together on first use and kept.  Why not a pair per scene (round 4, measured --
+// tools/exp_stream_pressure.py, profiles/r4/stream_pressure.txt): the runtime maps streams onto a handful of hardware queues,
+// least-loaded first, and a stream created when the other queues are taken shares a queue with the CALLER's stream.  The caller's
+// stream carries the accumulation kernels, each behind a wait for its chunk; a barrier waiting in a hardware queue blocks everything
+// submitted to that queue after it, so the next chunk -- submitted to the internal stream that shares the queue -- cannot start until
+// the previous one is done: the overlap is gone and the event traffic remains (C3: 32.2 -> 31.2 ms per call with no other scene
+// alive, 32.2 -> 33.3 with one, -> 31.4 with three, -> 33.4 with three and GPU_MAX_HW_QUEUES=8).  One pair created right after the
+// process's first stream gets two queues of its own and keeps them.  Scenes sharing the pair stay independent: a stream orders the
+// chunks queued to it, nothing in one scene's chunk waits for another scene's.
+struct SharedPair {
+  int device;
+  hipStream_t st[2];
+  int users; // scenes holding the pair (ezrt_trim destroys a pair nobody holds)
+};
+inline std::vector<SharedPair> g_shared_pairs; // (guarded by g_stream_pool_mu)
+inline hipError_t stream_shared_pair(hipStream_t out[2], int* device) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  *device = dev;
+  std::lock_guard<std::mutex> lock(g_stream_pool_mu);
+  for (SharedPair& q : g_shared_pairs)
+    if (q.device == dev) {
+      q.users++;
+      out[0] = q.st[0];
+      out[1] = q.st[1];
+      return hipSuccess;
+    }
+  SharedPair q;
+  q.device = dev;
+  q.users = 1;
+  e = hipStreamCreateWithFlags(&q.st[0], hipStreamNonBlocking);
+  if (e != hipSuccess) return e;
+  e = hipStreamCreateWithFlags(&q.st[1], hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    (void)hipStreamDestroy(q.st[0]);
+    return e;
+  }
+  g_shared_pairs.push_back(q);
+  out[0] = q.st[0];
+  out[1] = q.st[1];
+  return hipSuccess;
+}
+
+inline void stream_shared_release(int device) {
+  std::lock_guard<std::mutex> lock(g_stream_pool_mu);
+  for (SharedPair& q : g_shared_pairs)
+    if (q.device == device && q.users > 0) q.users--;
+}
+
 // Work still queued on the stream simply finishes; the next owner's work queues behind it.
 inline void stream_park(hipStream_t st, bool high_priority, int device) {
   if (!st) return;
@@ -57,6 +108,15 @@ inline int stream_pool_trim() {
   {
     std::lock_guard<std::mutex> lock(g_stream_pool_mu);
     all.swap(g_stream_pool);
+    for (size_t i = 0; i < g_shared_pairs.size();) { // the shared pairs no scene holds any more
+      if (g_shared_pairs[i].users > 0) {
+        i++;
+        continue;
+      }
+      all.push_back({g_shared_pairs[i].device, false, g_shared_pairs[i].st[0]});
+      all.push_back({g_shared_pairs[i].device, false, g_shared_pairs[i].st[1]});
+      g_shared_pairs.erase(g_shared_pairs.begin() + (long)i);
+    }
   }
   int prev = 0;
   (void)hipGetDevice(&prev);

@@ -52,7 +52,7 @@ def test_scene_after_a_destroyed_scene_renders_the_same_bits_at_the_same_speed(h
 
 @pytest.mark.gpu
 def test_two_scenes_alive_at_once_have_their_own_streams(hip):
-    """Two live scenes must not share the pooled streams (each takes its own pair); both render the single-scene bits."""
+    """Two live scenes share the device's pair of chunk streams but nothing else (scratch, events, counters); both render the single-scene bits."""
     from ezrt_amd import scene as S, scenes, trace
     bs = scenes.bunny_scene(subdiv=0, want_cache=True, hdr="shipped")
     eye, cam = S.camera(30, 10, 4.0)
@@ -60,7 +60,7 @@ def test_two_scenes_alive_at_once_have_their_own_streams(hip):
     a, b = bs.upload(hip), bs.upload(hip)
     fa, fb = a.render(p), b.render(p)
     a.close()
-    c = bs.upload(hip)   # takes a's parked streams while b is alive
+    c = bs.upload(hip)   # (round 4: the chunk streams are one pair per device, shared by the live scenes; each scene has its own scratch and events)
     fc, fb2 = c.render(p), b.render(p)
     b.close()
     c.close()
@@ -78,7 +78,7 @@ def test_trim_destroys_the_parked_streams_and_scenes_still_work_afterwards(hip):
     a = bs.upload(hip)
     fa = a.render(p)
     a.close()
-    assert hip.trim() >= 2      # a's two stream pairs were parked by close()
+    assert hip.trim() >= 2      # the device's pair of chunk streams: nobody holds it once `a` is closed
     assert hip.trim() == 0
     b = bs.upload(hip)          # creates its own streams again
     fb = b.render(p)

@@ -19,6 +19,8 @@ sc.counters_reset()
 t0 = time.perf_counter()
 for _ in range(3):
     sc.render_device(p, acc.data_ptr(), st)
+    if os.environ.get("SYNC_EACH"):   # (a host that synchronises after every call: no overlap across the call boundary)
+        torch.cuda.synchronize()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 3
 rays = sc.counters()["rays"] / 3
