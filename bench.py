@@ -192,16 +192,20 @@ def time_config(name, hip, torch, dev, stream, env, spp_override=0, check=True, 
         ms.append((time.perf_counter() - t0) * 1e3)
     rays = sc.counters()["rays"] // calls
     frame = acc.clone()                                   # what the timed calls left
+    # the trace launches' share: one more call with a timing-event pair around every trace launch, its chunks NOT overlapped
+    # (pipeline_calls 0 for this call: under overlap an event interval includes the launch's wait for wave slots)
     sc.set_option("launch_events", 1)
+    sc.set_option("pipeline_calls", 0)
     sc.render_device(p, acc.data_ptr(), stream)
     torch.cuda.synchronize()
     total_ms, trace_ms, n_launch = sc.last_render_ms()
     sc.set_option("launch_events", 0)
+    sc.set_option("pipeline_calls", 1)
     med = statistics.median(ms)
     out = {"workload": "%s: %d tris, %d BVH nodes, %dx%d, integrator %d, %d bounces, %d spp" %
                        (name, bs.tri.shape[0], bs.nodes.shape[0], W, H, cfg["integrator"], cfg["max_bounce"], cfg["spp"]),
            "Mrays_s": round(rays / (med * 1e-3) / 1e6, 2), "ms_per_frame": round(med, 3), "ms_per_frame_calls": [round(x, 3) for x in ms],
-           "rays": int(rays), "trace_ms": round(trace_ms, 3), "trace_launches": int(n_launch), "gpu_ms_with_launch_events": round(total_ms, 3),
+           "rays": int(rays), "trace_ms": round(trace_ms, 3), "trace_launches": int(n_launch), "gpu_ms_unpipelined_with_launch_events": round(total_ms, 3),
            "scene_build_s": round(t_build, 3), "scene_build": bs.build_stats if isinstance(bs.build_stats, dict) else None,
            "scene_create_s": round(t_create, 3), "first_call_s": round(t_first, 3),
            "non_finite_pixels": int((~torch.isfinite(frame[..., :3]).all(dim=2)).sum())}
