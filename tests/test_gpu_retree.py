@@ -127,3 +127,37 @@ def test_retree_keeps_the_counters_of_the_reference_tree(hip, oracle, bunny_smal
         sg.set_instrumentation(1)
         sg.render(p)
         assert sg.counters() == so.counters()
+
+
+@pytest.mark.gpu
+def test_scene_create_does_not_depend_on_the_host_thread_count(hip):
+    """ezrt_scene_create builds the device's tree over the leaves, the geometry / shading records and the pruning bounds on up
+    to 16 host threads (subtrees of the re-tree spliced behind its top: another numbering of the same tree).  One thread and
+    the default must give the same scene: the same pruning facts, the same answers and -- the schedule being a function of
+    the records -- the same work counters for the same rays (C3: 89 k leaves, enough for the parallel re-tree)."""
+    import os
+    bs = scenes.disney_grid_scene(subdiv=3)
+    eye, cam = S.camera(0, 15, 8)
+    rng = np.random.default_rng(3)
+    o = rng.uniform(-3, 3, (20000, 3)).astype(np.float32)
+    d = rng.normal(size=(20000, 3)).astype(np.float32)
+    rays = np.concatenate([o, d / np.linalg.norm(d, axis=1, keepdims=True)], 1).astype(np.float32)
+    got = []
+    for threads in ("1", None):
+        if threads is None:
+            os.environ.pop("EZRT_HOST_THREADS", None)
+        else:
+            os.environ["EZRT_HOST_THREADS"] = threads
+        try:
+            sc = bs.upload(hip)
+        finally:
+            os.environ.pop("EZRT_HOST_THREADS", None)
+        sc.set_option("audit_via_queue", 1)
+        tri, t = sc.query_hits(rays)
+        img = sc.render(trace.make_params(256, 256, eye, cam, 4, 3, spp=2))
+        got.append((sc.prune_info(), sc.stats(), tri, t, img))
+    a, b = got
+    assert a[0] == b[0] and a[1] == b[1]
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32))
+    assert np.array_equal(a[4].view(np.uint32), b[4].view(np.uint32))
+    assert (a[2] >= 0).mean() > 0.05
