@@ -161,3 +161,33 @@ def test_scene_create_does_not_depend_on_the_host_thread_count(hip):
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32))
     assert np.array_equal(a[4].view(np.uint32), b[4].view(np.uint32))
     assert (a[2] >= 0).mean() > 0.05
+
+
+@pytest.mark.gpu
+def test_a_leaf_with_two_parents_keeps_the_binary_kernel(hip, oracle, bunny_small):
+    """Caller arrays may reference a node from several parents (validation only asks parent < child).  The 4-wide records, the
+    re-tree and the tie tables hold ONE parent per node -- for leaves as well -- so such arrays must keep the binary
+    in-order kernel, which visits the shared leaf once per parent exactly as the reference's hitBVH would; results == oracle."""
+    nodes = bunny_small.nodes.copy()
+    is_leaf = nodes[:, 3] > 0
+    # an inner node q whose LEFT child is a leaf, and a leaf L with a larger id somewhere else: q's left child becomes L
+    cand_q = [i for i in range(2, nodes.shape[0]) if not is_leaf[i] and is_leaf[int(nodes[i, 0])]]
+    q = cand_q[len(cand_q) // 3]
+    leaves_after = [i for i in range(int(nodes[q, 0]) + 50, nodes.shape[0]) if is_leaf[i]]
+    L = leaves_after[0]
+    nodes[q, 0] = np.float32(L)
+    sg, so = hip.scene_create(bunny_small.tri, nodes), oracle.scene_create(bunny_small.tri, nodes)
+    assert sg.prune_info()["records4"] == 0          # no 4-wide records: the binary kernel traces this scene
+    hdr = scenes.synthetic_hdr(64, 32)
+    sg.set_env(hdr, None, 1)
+    so.set_env(hdr, None, 1)
+    eye, cam = S.camera(0, 0, 4)
+    p = trace.make_params(96, 96, eye, cam, 50, 3, spp=2)
+    assert np.array_equal(sg.render(p).view(np.uint32), so.render(p).view(np.uint32))
+    sg.set_instrumentation(1)
+    so.set_instrumentation(1)
+    sg.counters_reset()
+    so.counters_reset()
+    sg.render(p)
+    so.render(p)
+    assert sg.counters() == so.counters()
