@@ -29,6 +29,19 @@ def bench(name, make):
     t2, n2, _ = build.build_sah(tri, 8)
     th, nh = hs.encode()
     r["gpu_sah_equals_host_sah_bits"] = bool(np.array_equal(t2.view(np.uint32), th.view(np.uint32)) and np.array_equal(n2.view(np.uint32), nh.view(np.uint32)))
+    # the default path of round 4 (GPU SAH from 10^5 triangles on) and ezrt_scene_create on 1 host thread and on the default number
+    t0 = time.perf_counter()
+    auto = make(gpu_build=None) if name == "C5" else make()
+    r["scene_function_total_s_default_builder"] = round(time.perf_counter() - t0, 3)
+    r["default_builder"] = "gpu" if "gpu_build_ms" in auto.build_stats else "host"
+    for label, env in (("one_thread", "1"), ("default_threads", None)):
+        if env:
+            os.environ["EZRT_HOST_THREADS"] = env
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter(); sc = auto.upload(hip); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0); sc.close()
+        os.environ.pop("EZRT_HOST_THREADS", None)
+        r["scene_create_s_" + label] = round(sorted(ts)[1], 3)
     out["sets"].append(r)
     print(json.dumps(r), file=sys.stderr)
 
