@@ -123,6 +123,8 @@ def physical_roofline(trace_ms_per_step, launches_per_step):
         "source": "%s @ %s" % (path, pm["source_sha"]),
     }
     out["traffic_per_launch"] = int(k["hbm_bytes"] / max(1, launches_per_step))
+    if pm.get("all_kernels"):
+        out["all_kernels_valu_wave_instr_per_step"] = int(pm["all_kernels"]["valu_wave_instr_per_step"])
     return out, None
 
 
@@ -612,6 +614,15 @@ def main():
                                     "(tools/exp_valu_issue.hip, profiles/r2/valu_issue_microbench.txt); peak_nominal = 256 CUs x 4 SIMDs x "
                                     "2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)",
                        "traffic": phys["traffic_per_launch"], "ceilings": fr, "physical": phys})
+            if phys.get("all_kernels_valu_wave_instr_per_step"):
+                # the CHIP over a whole step, every kernel: what overlapping consecutive calls changes (the dominant kernel's own fraction
+                # above is measured with the calls one at a time and does not move)
+                av = phys["all_kernels_valu_wave_instr_per_step"]
+                rf["whole_step"] = {"valu_wave_instr_all_kernels": av,
+                                    "issue_frac_in_the_timed_windows": round(av / (ms_per_step * 1e-3) / 1e12 / VALU_ISSUE_PEAK_T, 4),
+                                    "issue_frac_one_call_at_a_time": round(av / (ms_total * 1e-3) / 1e12 / VALU_ISSUE_PEAK_T, 4),
+                                    "note": "all kernels' VALU wave-instructions per step / step time / %.3f T: ms_per_step of the median window "
+                                            "(calls queued back to back, chunks overlapped) vs the median GPU time of a call between two synchronisations" % VALU_ISSUE_PEAK_T}
         else:
             rf.update({"bound": "valu_issue", "achieved": None, "peak": VALU_ISSUE_PEAK_T, "unit": "T wave-instr/s", "frac": None,
                        "peak_measured": VALU_ISSUE_PEAK_T, "peak_nominal": round(VALU_ISSUE_PEAK_NOMINAL_T, 4),

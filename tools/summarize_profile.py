@@ -28,7 +28,43 @@ def short(name):
     return n.split("(")[0]
 
 
+def all_kernels_per_step(kernels):
+    """kernels: {short name: {counter: {"mean_per_dispatch", "dispatches"}}} (the *_pmc.json form) -> VALU wave-instructions of ONE timed step
+    summed over every kernel of the timed pipeline (the launches of the one instrumented step -- FULLCTR variants, raygen_kernel,
+    inner_rel_kernel, the binary traceq_kernel<true,..> -- are left out); steps profiled = dispatches of the primary trace kernel."""
+    steps = 0
+    for k, v in kernels.items():
+        if k.startswith("traceq4_kernel") and "SQ_INSTS_VALU" in v and ", true, false" in k.split("<", 1)[1][:14]:
+            steps = max(steps, v["SQ_INSTS_VALU"]["dispatches"])
+    if not steps:
+        return None
+    per, total = {}, 0.0
+    for k, v in kernels.items():
+        c = v.get("SQ_INSTS_VALU")
+        if not c:
+            continue
+        args = k.split("<", 1)[1] if "<" in k else ""
+        instrumented = k.startswith(("raygen", "inner_rel", "inner4_rel")) or (k.startswith("traceq_kernel") and args.startswith("true")) or \
+            (k.startswith("shade") and ", true," in args)
+        if instrumented:
+            continue
+        x = c["mean_per_dispatch"] * c["dispatches"] / steps
+        if x > 0:
+            per[k] = int(x)
+            total += x
+    return {"valu_wave_instr_per_step": int(total), "steps_profiled": steps, "per_kernel": per,
+            "note": "sum over every kernel of a timed step (dispatch counts / render calls profiled); the instrumented step's kernels are left out"}
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--add-all-kernels":   # derive the field from an already collected <dir>/final_pmc.json
+        d = sys.argv[2]
+        pm = json.load(open(os.path.join(d, "final_pmc.json")))
+        sm = json.load(open(os.path.join(d, "pmc_summary.json")))
+        sm["all_kernels"] = all_kernels_per_step(pm["kernels"])
+        json.dump(sm, open(os.path.join(d, "pmc_summary.json"), "w"), indent=1)
+        print(sm["all_kernels"]["valu_wave_instr_per_step"])
+        return
     src, dst = sys.argv[1], sys.argv[2]
     launches_per_step = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     os.makedirs(os.path.dirname(dst), exist_ok=True)
@@ -69,7 +105,7 @@ def main():
         per_step["hbm_bytes"] = (2.0 * per_step.get("FETCH_SIZE", 0.0) + per_step.get("WRITE_SIZE", 0.0)) * 1024.0
         per_step["l2_bytes"] = per_step.get("TCP_TCC_READ_REQ_sum", 0.0) * 64.0
         per_step["lds_bytes"] = per_step.get("SQ_INSTS_LDS", 0.0) * 64.0 * 16.0
-        summary = {"source_sha": out["source_sha"], "source": dst + "_pmc.json", "dominant": per_step,
+        summary = {"source_sha": out["source_sha"], "source": dst + "_pmc.json", "dominant": per_step, "all_kernels": all_kernels_per_step(out["kernels"]),
                    "note": "per-step sums over the dominant kernel's launches (1 + max_bounce per step); see tools/summarize_profile.py"}
         json.dump(summary, open(os.path.join(os.path.dirname(os.path.abspath(dst)), "pmc_summary.json"), "w"), indent=1)
         print("dominant", dom, "per step: VALU %.4g SALU %.4g HBM %.4g B L2 %.4g B" % (
