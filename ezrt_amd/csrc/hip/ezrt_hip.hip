@@ -9,6 +9,9 @@
 #include <cstdlib>
 #include <array>
 #include <cstring>
+#include <exception>
+#include <new>
+#include <system_error>
 #include <chrono>
 #include <map>
 #include <string>
@@ -159,6 +162,14 @@ struct Tuning {
                            // launches free wave slots, and a pool dealt statically to a workgroup that arrives late is the launch's tail.
                            // With the queues all dynamic pipelining gains on every config (C3 +3.0 %, C4 +2.6 %, C5 +1.8 %, C2 +13 %); with
                            // the unpipelined optimum of 50 it lost 1-5 % on C3 / C4 / C5 (profiles/r4/pipeline_calls_ab.txt)
+  int handover = 1;        // traceq4_kernel: once the queue is exhausted, idle lanes take the prefetched (unstarted) rays of lanes of their wave that
+                           // are still traversing (TraceQ4Args::handover)
+  int xsteal = 0;          // (MEASURED SLOWER, see DESIGN.md section 5 "Round 5": default off) traceq4_kernel steals pending subtrees ACROSS waves, inside groups of workgroups, through rings in global memory
+                           // (ezrt_traceq4.h "Stealing across waves"; the launches that prune with the nearest-first order, i.e. the default
+                           // schedule); 0: within a wave only
+  int xsteal_stock = 16;   // ... entries a group's donors keep published
+  int xsteal_min_idle = 40; // ... idle lanes (beyond what the wave's own pending rows can feed) from which a wave claims published entries
+  int xsteal_groups = 256; // ... groups per launch (a power of two, 16 .. 512: workgroup b belongs to group b mod groups)
   int audit_via_queue = 0; // 1: ezrt_query_hits and ezrt_render_paths run through the TIMED kernels (traceq_kernel with
                            // the template, LDS layout, stealing and redo launch of a render call + the streaming shading
                            // stages) instead of the in-order audit kernels; 2 (query only): additionally treat the rays as
@@ -217,6 +228,11 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"bounce_scatter", &Tuning::bounce_scatter, 0, 2},
                               {"pipeline_calls", &Tuning::pipeline_calls, 0, 2},
                               {"static_pct_pipelined", &Tuning::static_pct_pipelined, 0, 95},
+                              {"handover", &Tuning::handover, 0, 1},
+                              {"xsteal", &Tuning::xsteal, 0, 1},
+                              {"xsteal_stock", &Tuning::xsteal_stock, 1, 256},
+                              {"xsteal_groups", &Tuning::xsteal_groups, 16, 512},
+                              {"xsteal_min_idle", &Tuning::xsteal_min_idle, 1, 64},
                               {"audit_via_queue", &Tuning::audit_via_queue, 0, 2}};
 Tuning tuning_from_env() {
   Tuning t;
@@ -246,7 +262,9 @@ struct Pipe {
   DevBuf<uint32_t> qcounts; // [0..63] path counts per stage, [64..99] trace queue heads, [100..115] debug,
                             // [120] redo count, [121] redo queue head
   DevBuf<uint32_t> redo_slots;
-  DevBuf<uint32_t> qheads;      // traceq reservation counters: [launch slot][TRACE_HEADS][TRACE_HEAD_STRIDE]
+  DevBuf<uint32_t> qheads;      // traceq reservation counters: [launch slot][TRACE_HEADS][TRACE_HEAD_STRIDE], then the control words of
+                                // cross-wave stealing: [group][XS_CTL_WORDS] (QHEADS_WORDS in all; zeroed per chunk)
+  DevBuf<unsigned long long> xs_ring; // cross-wave stealing: published subtrees, [group][XS_GRING] (all zero between launches)
   DevBuf<float4> inner_rel;     // inner records translated by -eye (primary rays)
   DevBuf<float4> inner4_rel;    // 4-wide records translated by -eye
   DevBuf<uint4> defer_list;     // split shading: paths with a surface interaction, per workgroup
@@ -314,8 +332,9 @@ struct EzrtScene {
   Tuning tune = tuning_from_env();
   // timing
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-  hipEvent_t ev_trace[MAX_TRACE_EVENTS][2];
+  hipEvent_t ev_trace[MAX_TRACE_EVENTS][2] = {};
   int n_trace_events = 0, n_trace_launches = 0, n_trace_events_created = 0;
+  bool events_ready = false; // ensure_events ran to its end
   bool timed = false;
 
   DevScene dev() const {
@@ -355,12 +374,30 @@ void parallel_for(int n, int grain, F f) {
     f(0, n, 0);
     return;
   }
+  // Nothing may leave through the C ABI as an exception: a worker's exception (std::bad_alloc in a lambda's vector)
+  // is carried to the caller's thread, a thread that cannot be created (std::system_error under a thread cap) has its range
+  // run inline; every thread that did start is joined before anything is rethrown -- ezrt_scene_create turns it into an error code.
   std::vector<std::thread> th;
+  std::vector<std::exception_ptr> err((size_t)nt);
+  th.reserve((size_t)nt);
   for (int k = 0; k < nt; k++) {
     const int lo = (int)((long long)n * k / nt), hi = (int)((long long)n * (k + 1) / nt);
-    th.emplace_back([=, &f] { f(lo, hi, k); });
+    auto body = [=, &f, &err] {
+      try {
+        f(lo, hi, k);
+      } catch (...) {
+        err[(size_t)k] = std::current_exception();
+      }
+    };
+    try {
+      th.emplace_back(body);
+    } catch (const std::system_error&) {
+      body();
+    }
   }
   for (auto& t : th) t.join();
+  for (auto& e : err)
+    if (e) std::rethrow_exception(e);
 }
 constexpr int PAR_MAX = 16; // threads of parallel_for at most (per-thread partial results are arrays of this size)
 
@@ -648,16 +685,20 @@ void launch_trace(const TraceArgs& a, int mode, dim3 grid, size_t lds, hipStream
   }
 }
 
+// Events and the shared stream pair of a scene, created on its first render call.  Idempotent and incremental: a
+// step that fails leaves what exists in place -- counted, so that ezrt_scene_destroy releases it -- and the next call resumes
+// there; `events_ready` is only set after the last step, so no call ever runs with a null stream or event.
 int ensure_events(EzrtScene* s) {
-  if (s->ev_begin) return 0;
-  HIP_TRY(hipEventCreate(&s->ev_begin));
-  HIP_TRY(hipEventCreate(&s->ev_end));
-  for (int i = 0; i < 64; i++) {
-    HIP_TRY(hipEventCreate(&s->ev_trace[i][0]));
-    HIP_TRY(hipEventCreate(&s->ev_trace[i][1]));
+  if (s->events_ready) return 0;
+  if (!s->ev_begin) HIP_TRY(hipEventCreate(&s->ev_begin));
+  if (!s->ev_end) HIP_TRY(hipEventCreate(&s->ev_end));
+  while (s->n_trace_events_created < 64) {
+    const int i = s->n_trace_events_created;
+    if (!s->ev_trace[i][0]) HIP_TRY(hipEventCreate(&s->ev_trace[i][0]));
+    if (!s->ev_trace[i][1]) HIP_TRY(hipEventCreate(&s->ev_trace[i][1]));
+    s->n_trace_events_created = i + 1;
   }
-  s->n_trace_events_created = 64;
-  {
+  if (!s->pipe[0].stream) {
     // (the device's shared pair: ezrt_streams.h says why the two streams the chunks alternate between are not the scene's own)
     hipStream_t pair[2];
     int dev = 0;
@@ -668,11 +709,12 @@ int ensure_events(EzrtScene* s) {
   }
   for (Pipe& q : s->pipe) {
     // (the side stream of the redo launches -- knob redo_overlap, off by default -- is taken from the pool when first needed)
-    HIP_TRY(hipEventCreateWithFlags(&q.ev_main, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&q.ev_redo, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&q.ev_done, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&q.ev_free, hipEventDisableTiming));
+    if (!q.ev_main) HIP_TRY(hipEventCreateWithFlags(&q.ev_main, hipEventDisableTiming));
+    if (!q.ev_redo) HIP_TRY(hipEventCreateWithFlags(&q.ev_redo, hipEventDisableTiming));
+    if (!q.ev_done) HIP_TRY(hipEventCreateWithFlags(&q.ev_done, hipEventDisableTiming));
+    if (!q.ev_free) HIP_TRY(hipEventCreateWithFlags(&q.ev_free, hipEventDisableTiming));
   }
+  s->events_ready = true;
   return 0;
 }
 
@@ -817,23 +859,33 @@ void launch_traceq4_v(EzrtScene* s, const TraceCfg& c, const TraceQ4Args& q, hip
   // rays with an exactly-zero direction component stay in this kernel (SEMI) where they come in numbers: the env shadow
   // rays of the MIS integrators' bounce stages (two rays per path); knob semi: 0 never, 2 every launch without a common origin
   const bool semi = !REL && !GEN && (s->tune.semi == 2 || (s->tune.semi == 1 && q.q.rays_per_path == 2u));
+  // cross-wave stealing (knob xsteal; q.xs_ctl): variants of the default schedule's kernels -- pruning with the nearest-first order
+  const bool xs = q.xs_ctl != nullptr && prune == 2;
   if (prune || GEN || semi) { // (these variants exist for the two register budgets the launches use: 7 and 6 waves per SIMD)
     // (the scattered draw exists for the default schedule of the bounce stages: pruning with the nearest-first order, no log)
     if (!REL && !GEN && !LOG && prune == 2 && q.gscat_shift != 0u && trace_wps < 7) {
-      if (semi) hipLaunchKernelGGL((traceq4_kernel<6, false, false, 2, false, true, true>), grid, block, c.lds_t, st, q);
-      else hipLaunchKernelGGL((traceq4_kernel<6, false, false, 2, false, false, true>), grid, block, c.lds_t, st, q);
+      if (xs) {
+        if (semi) hipLaunchKernelGGL((traceq4_kernel<6, false, false, 2, false, true, true, true>), grid, block, c.lds_t, st, q);
+        else hipLaunchKernelGGL((traceq4_kernel<6, false, false, 2, false, false, true, true>), grid, block, c.lds_t, st, q);
+      } else {
+        if (semi) hipLaunchKernelGGL((traceq4_kernel<6, false, false, 2, false, true, true>), grid, block, c.lds_t, st, q);
+        else hipLaunchKernelGGL((traceq4_kernel<6, false, false, 2, false, false, true>), grid, block, c.lds_t, st, q);
+      }
       return;
     }
     if (semi) {
-      if (prune == 2) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 2, false, !REL>), grid, block, c.lds_t, st, q);
+      if (xs) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 2, false, !REL, false, true>), grid, block, c.lds_t, st, q);
+      else if (prune == 2) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 2, false, !REL>), grid, block, c.lds_t, st, q);
       else if (prune == 1) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 1, false, !REL>), grid, block, c.lds_t, st, q);
       else hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 0, false, !REL>), grid, block, c.lds_t, st, q);
     } else if (trace_wps >= 7) {
-      if (prune == 2) hipLaunchKernelGGL((traceq4_kernel<7, REL, LOG, 2, GEN>), grid, block, c.lds_t, st, q);
+      if (xs) hipLaunchKernelGGL((traceq4_kernel<7, REL, LOG, 2, GEN, false, false, true>), grid, block, c.lds_t, st, q);
+      else if (prune == 2) hipLaunchKernelGGL((traceq4_kernel<7, REL, LOG, 2, GEN>), grid, block, c.lds_t, st, q);
       else if (prune == 1) hipLaunchKernelGGL((traceq4_kernel<7, REL, LOG, 1, GEN>), grid, block, c.lds_t, st, q);
       else hipLaunchKernelGGL((traceq4_kernel<7, REL, LOG, 0, GEN>), grid, block, c.lds_t, st, q);
     } else {
-      if (prune == 2) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 2, GEN>), grid, block, c.lds_t, st, q);
+      if (xs) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 2, GEN, false, false, true>), grid, block, c.lds_t, st, q);
+      else if (prune == 2) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 2, GEN>), grid, block, c.lds_t, st, q);
       else if (prune == 1) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 1, GEN>), grid, block, c.lds_t, st, q);
       else hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 0, GEN>), grid, block, c.lds_t, st, q);
     }
@@ -850,6 +902,27 @@ void launch_traceq4_rel(EzrtScene* s, const TraceCfg& c, const TraceQ4Args& q, h
   if (q.q.wave_log) launch_traceq4_v<REL, true, GEN>(s, c, q, st); // (debug_stages=2)
   else launch_traceq4_v<REL, false, GEN>(s, c, q, st);
 }
+// qheads: 81 launch slots of reservation counters, then XS_CTL_WORDS control words of cross-wave stealing per group (shared by the
+// stages of a chunk: a launch leaves every group with tail == head and nobody counted)
+constexpr size_t QHEAD_SLOT_WORDS = (size_t)TRACE_HEADS * TRACE_HEAD_STRIDE;
+constexpr size_t QHEADS_WORDS = 81 * QHEAD_SLOT_WORDS + (size_t)XS_GROUPS_MAX * XS_CTL_WORDS;
+inline uint32_t* xs_ctl_of(const Pipe& pp) { return pp.qheads.p + 81 * QHEAD_SLOT_WORDS; }
+// the rings of published subtrees: all zero between launches (a taker zeroes what it takes), so zeroed once, when allocated
+hipError_t ensure_xs_ring(Pipe& pp, hipStream_t st) {
+  const size_t n = (size_t)XS_GROUPS_MAX * XS_GRING;
+  if (pp.xs_ring.n >= n) return hipSuccess;
+  hipError_t e = pp.xs_ring.ensure(n);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(pp.xs_ring.p, 0, n * sizeof(unsigned long long), st);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(st); // (the chunk may run on another stream than `st`; once per scratch set)
+}
+inline uint32_t xs_groups(const EzrtScene* s) { // the knob, rounded down to a power of two
+  uint32_t g = 16u;
+  while (g * 2u <= (uint32_t)s->tune.xsteal_groups && g * 2u <= XS_GROUPS_MAX) g *= 2u;
+  return g;
+}
+
 // t: the stage's queue arguments as for the binary kernel (knobs already filled); rel: 4-wide records translated by
 // t.origin (or NULL)
 // gen (or NULL): the chunk's stage-0 arguments when the launch generates its primary rays itself (needs rel)
@@ -891,10 +964,22 @@ void fill_traceq4_args(const EzrtScene* s, const TraceCfg& c4, const TraceQArgs&
   // C2 +2.7 % (trace launches 1.39 -> 1.345 ms), C3 -0.5 % (noise); the MIS integrators' queues (two rays per path sharing an
   // origin, env shadow rays that are coherent by construction) LOSE 1.3 % (C4) and 2.8 % (C5) with it: 2 = those too
   A.gscat_shift = (!rel && !gen && !t.slot_map && (s->tune.bounce_scatter == 2 || (s->tune.bounce_scatter == 1 && t.rays_per_path == 1u))) ? 3u : 0u;
+  A.xs_ctl = nullptr; // (cross-wave stealing: set by launch_traceq4_cfg for the launches that have a ring)
+  A.xs_ring = nullptr;
+  A.xs_stock = (uint32_t)s->tune.xsteal_stock;
+  A.xs_gmask = xs_groups(s) - 1u;
+  A.xs_min_idle = (uint32_t)s->tune.xsteal_min_idle;
+  A.handover = (s->tune.handover && t.steal) ? 1u : 0u;
 }
-void launch_traceq4_cfg(EzrtScene* s, const TraceCfg& c4, const TraceQArgs& t, const float4* rel, hipStream_t st, const WfArgs* gen = nullptr) {
+// xs_ctl / xs_ring (or NULL): this launch's control words and the scratch set's ring of published subtrees (knob xsteal)
+void launch_traceq4_cfg(EzrtScene* s, const TraceCfg& c4, const TraceQArgs& t, const float4* rel, hipStream_t st, const WfArgs* gen = nullptr,
+                        uint32_t* xs_ctl = nullptr, unsigned long long* xs_ring = nullptr) {
   TraceQ4Args A;
   fill_traceq4_args(s, c4, t, rel, gen, A);
+  if (s->tune.xsteal && t.steal && !t.slot_map && xs_ctl && xs_ring) {
+    A.xs_ctl = xs_ctl;
+    A.xs_ring = xs_ring;
+  }
   if (rel && gen) launch_traceq4_rel<true, true>(s, c4, A, st);
   else if (rel) launch_traceq4_rel<true, false>(s, c4, A, st);
   else launch_traceq4_rel<false, false>(s, c4, A, st);
@@ -1030,8 +1115,9 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
   // [0..63] paths per stage, [64..99] queue heads, [100..119] debug, [120,121] packet redo,
   // [128..] redo counts per stage, [192..] redo queue heads per stage
   constexpr size_t HEAD_SLOT = (size_t)TRACE_HEADS * TRACE_HEAD_STRIDE; // launch slots: stage b, redo 40 + b, packet redo 80
-  HIP_TRY(pp.qheads.ensure(81 * HEAD_SLOT)); // (both zeroed by raygen_kernel: ChunkPrologue)
+  HIP_TRY(pp.qheads.ensure(QHEADS_WORDS)); // (both zeroed by raygen_kernel: ChunkPrologue)
   HIP_TRY(pp.qcounts.ensure(320));
+  if (s->tune.xsteal) HIP_TRY(ensure_xs_ring(pp, st));
   {
     int rc_cu = ensure_num_cus(s);
     if (rc_cu) return rc_cu;
@@ -1103,7 +1189,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
   const TraceCfg cfg4_rel = wide ? trace_cfg4(s, true) : TraceCfg(), cfg4_abs = wide ? trace_cfg4(s, false) : TraceCfg();
   ChunkPrologue pro;
   pro.zero_a = pp.qheads.p;
-  pro.n_zero_a = (uint32_t)(81 * HEAD_SLOT);
+  pro.n_zero_a = (uint32_t)QHEADS_WORDS;
   pro.zero_b = pp.qcounts.p;
   pro.n_zero_b = 320u;
   pro.inner4 = nullptr;
@@ -1265,9 +1351,10 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     int e = tu.launch_events ? s->n_trace_events : MAX_TRACE_EVENTS;
     if (e < MAX_TRACE_EVENTS) {
       while (s->n_trace_events_created <= e) { // (calls with more than 64 timed launches: created on first use)
-        HIP_TRY(hipEventCreate(&s->ev_trace[s->n_trace_events_created][0]));
-        HIP_TRY(hipEventCreate(&s->ev_trace[s->n_trace_events_created][1]));
-        s->n_trace_events_created++;
+        const int ne = s->n_trace_events_created;
+        if (!s->ev_trace[ne][0]) HIP_TRY(hipEventCreate(&s->ev_trace[ne][0]));
+        if (!s->ev_trace[ne][1]) HIP_TRY(hipEventCreate(&s->ev_trace[ne][1]));
+        s->n_trace_events_created = ne + 1;
       }
       HIP_TRY(hipEventRecord(s->ev_trace[e][0], st));
     }
@@ -1305,7 +1392,8 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     } else {
       if (wide) {
         const bool rel = b == 0 && tu.rel_boxes;
-        launch_traceq4_cfg(s, rel ? cfg4_rel : cfg4_abs, t, rel ? pp.inner4_rel.p : nullptr, st, (rel && gen_primary) ? &a : nullptr);
+        launch_traceq4_cfg(s, rel ? cfg4_rel : cfg4_abs, t, rel ? pp.inner4_rel.p : nullptr, st, (rel && gen_primary) ? &a : nullptr,
+                           xs_ctl_of(pp), pp.xs_ring.p);
       }
       else launch_traceq(t);
       if (t.steal || wide) { // rays that met an exact distance tie, or (4-wide) are not tame -- normally none: reference order, plain stores
@@ -1403,7 +1491,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
         unsigned long long t0 = ~0ull;
         for (size_t i = 0; i < nw; i++)
           if (w[i * 8] && w[i * 8] < t0) t0 = w[i * 8];
-        unsigned long long s_it = 0, s_is = 0, s_il = 0, s_ll = 0, s_lr = 0, s_busy = 0, s_rf = 0, s_st = 0;
+        unsigned long long s_it = 0, s_is = 0, s_il = 0, s_ll = 0, s_lr = 0, s_busy = 0, s_rf = 0, s_st = 0, s_xg = 0, s_xt = 0;
         std::vector<double> endt, life, its, rays, startt, exht, after;
         for (size_t i = 0; i < nw; i++)
           if (w[i * 8]) {
@@ -1421,7 +1509,9 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
             s_il += w[i * 8 + 3] >> 32;
             s_ll += (uint32_t)w[i * 8 + 4];
             s_lr += w[i * 8 + 4] >> 32;
-            s_busy += w[i * 8 + 5];
+            s_busy += (uint32_t)w[i * 8 + 5];
+            s_xg += (w[i * 8 + 5] >> 32) & 0xffffu;
+            s_xt += w[i * 8 + 5] >> 48;
             s_rf += (uint32_t)w[i * 8 + 6];
             s_st += w[i * 8 + 6] >> 32;
           }
@@ -1440,8 +1530,8 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
         if (!exht.empty())
           fprintf(stderr, "[ezrt]   queue found empty at us p10 %.1f p50 %.1f p90 %.1f max %.1f | a wave then runs on for us p10 %.1f p50 %.1f p90 %.1f max %.1f\n",
                   pct(exht, 0.1), pct(exht, 0.5), pct(exht, 0.9), pct(exht, 1.0), pct(after, 0.1), pct(after, 0.5), pct(after, 0.9), pct(after, 1.0));
-        fprintf(stderr, "[ezrt]   refill block in %.0f %% of the iterations, steal block in %.0f %%\n", 100.0 * (double)s_rf / (double)(s_it ? s_it : 1),
-                100.0 * (double)s_st / (double)(s_it ? s_it : 1));
+        fprintf(stderr, "[ezrt]   refill block in %.0f %% of the iterations, steal block in %.0f %% | across waves: %llu subtrees published, %llu claimed\n",
+                100.0 * (double)s_rf / (double)(s_it ? s_it : 1), 100.0 * (double)s_st / (double)(s_it ? s_it : 1), s_xg, s_xt);
       }
       uint32_t dbg[3] = {0, 0, 0};
       HIP_TRY(hipMemcpy(dbg, pp.qcounts.p + 100 + 4 * (b & 3), sizeof dbg, hipMemcpyDeviceToHost));
@@ -1450,6 +1540,20 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
         uint32_t redo_n = 0;
         HIP_TRY(hipMemcpy(&redo_n, pp.qcounts.p + 128 + b, sizeof redo_n, hipMemcpyDeviceToHost));
         fprintf(stderr, "[ezrt] stage %d: %u rays re-traced in reference order (exact ties / not tame)\n", b, redo_n);
+        if (wide && s->tune.xsteal) { // cross-wave stealing: the groups' control words as the launches so far left them (cumulative over the chunk)
+          const uint32_t ng = xs_groups(s);
+          std::vector<uint32_t> xc((size_t)ng * XS_CTL_WORDS);
+          HIP_TRY(hipMemcpy(xc.data(), xs_ctl_of(pp), xc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+          unsigned long long pub = 0, clm = 0, busy = 0, err = 0;
+          for (uint32_t g = 0; g < ng; g++) {
+            pub += xc[(size_t)g * XS_CTL_WORDS];
+            clm += xc[(size_t)g * XS_CTL_WORDS + 1];
+            busy += xc[(size_t)g * XS_CTL_WORDS + XS_BUSY];
+            err += xc[(size_t)g * XS_CTL_WORDS + XS_ERR];
+          }
+          fprintf(stderr, "[ezrt] stage %d: across waves (%u groups, chunk so far): %llu subtrees published, %llu claimed, lost entries %llu, busy count left %llu\n",
+                  b, ng, pub, clm, err, busy);
+        }
       }
       fprintf(stderr, "[ezrt] stage %d: paths_in %u paths_out %u | cum rays %llu pops %llu inner %llu tris %llu | max/ray pops %u tris %u iters %u\n", b, q[0],
               q[1], c[0], c[1], c[2], c[3], dbg[0], dbg[1], dbg[2]);
@@ -1480,9 +1584,19 @@ const char* ezrt_last_error(void) { return g_err; }
 __attribute__((visibility("hidden"))) int ezrt_fail_msg(int code, const char* msg) { return fail(code, "%s", msg); }
 const char* ezrt_backend(void) { return "hip:gfx950"; }
 
+static int scene_create_impl(const float* tri, int n_tri, const float* nodes, int n_nodes, EzrtScene** out);
 int ezrt_scene_create(const float* tri, int n_tri, const float* nodes, int n_nodes, EzrtScene** out) {
   if (!out) return fail(EZRT_ERR_INVALID, "out is NULL");
   *out = nullptr;
+  try { // (host-side allocations and worker threads: no exception crosses the C ABI)
+    return scene_create_impl(tri, n_tri, nodes, n_nodes, out);
+  } catch (const std::bad_alloc&) {
+    return fail(EZRT_ERR_NOMEM, "out of host memory while building the scene's records");
+  } catch (const std::exception& e) {
+    return fail(EZRT_ERR_DEVICE, "scene creation failed: %s", e.what());
+  }
+}
+static int scene_create_impl(const float* tri, int n_tri, const float* nodes, int n_nodes, EzrtScene** out) {
   if (!tri || !nodes || n_tri <= 0 || n_nodes <= 0) return fail(EZRT_ERR_INVALID, "empty scene arrays");
   if (n_tri >= (1 << 24) || n_nodes >= (1 << 24))
     return fail(EZRT_ERR_UNSUPPORTED, "counts >= 2^24 are not exact in the float encoding");
@@ -2087,22 +2201,21 @@ int ezrt_trim(void) { return ezh::stream_pool_trim(); }
 
 void ezrt_scene_destroy(EzrtScene* s) {
   if (!s) return;
-  if (s->ev_begin) {
-    (void)hipEventDestroy(s->ev_begin);
-    (void)hipEventDestroy(s->ev_end);
-    for (Pipe& q : s->pipe) {
-      ezh::stream_park(q.side, true, q.stream_device); // (q.stream is the device's shared pair: released below, not parked)
-      if (q.ev_main) (void)hipEventDestroy(q.ev_main);
-      if (q.ev_redo) (void)hipEventDestroy(q.ev_redo);
-      if (q.ev_done) (void)hipEventDestroy(q.ev_done);
-      if (q.ev_free) (void)hipEventDestroy(q.ev_free);
-    }
-    for (int i = 0; i < s->n_trace_events_created; i++) {
-      (void)hipEventDestroy(s->ev_trace[i][0]);
-      (void)hipEventDestroy(s->ev_trace[i][1]);
-    }
-    if (s->pipe[0].stream) ezh::stream_shared_release(s->pipe[0].stream_device);
+  // (whatever ensure_events got to create: it may have stopped half way)
+  if (s->ev_begin) (void)hipEventDestroy(s->ev_begin);
+  if (s->ev_end) (void)hipEventDestroy(s->ev_end);
+  for (Pipe& q : s->pipe) {
+    if (q.side) ezh::stream_park(q.side, true, q.stream_device); // (q.stream is the device's shared pair: released below, not parked)
+    if (q.ev_main) (void)hipEventDestroy(q.ev_main);
+    if (q.ev_redo) (void)hipEventDestroy(q.ev_redo);
+    if (q.ev_done) (void)hipEventDestroy(q.ev_done);
+    if (q.ev_free) (void)hipEventDestroy(q.ev_free);
   }
+  for (int i = 0; i < MAX_TRACE_EVENTS; i++) {
+    if (s->ev_trace[i][0]) (void)hipEventDestroy(s->ev_trace[i][0]);
+    if (s->ev_trace[i][1]) (void)hipEventDestroy(s->ev_trace[i][1]);
+  }
+  if (s->pipe[0].stream) ezh::stream_shared_release(s->pipe[0].stream_device);
   delete s;
 }
 
@@ -2447,8 +2560,9 @@ int ezrt_query_hits(EzrtScene* s, const float* rays, int n_rays, int32_t* tri_id
       HIP_TRY(pp.redo_flag.ensure(n));
       HIP_TRY(hipMemset(pp.redo_flag.p, 0, pp.redo_flag.n * sizeof(uint32_t)));
     }
-    HIP_TRY(pp.qheads.ensure(81 * HEAD_SLOT));
-    HIP_TRY(hipMemset(pp.qheads.p, 0, 81 * HEAD_SLOT * sizeof(uint32_t)));
+    HIP_TRY(pp.qheads.ensure(QHEADS_WORDS));
+    HIP_TRY(hipMemset(pp.qheads.p, 0, QHEADS_WORDS * sizeof(uint32_t)));
+    if (s->tune.xsteal) HIP_TRY(ensure_xs_ring(pp, nullptr));
     HIP_TRY(pp.qcounts.ensure(320));
     HIP_TRY(hipMemset(pp.qcounts.p, 0, 320 * sizeof(uint32_t)));
     const unsigned g1 = (unsigned)((n + 255) / 256);
@@ -2501,7 +2615,7 @@ int ezrt_query_hits(EzrtScene* s, const float* rays, int n_rays, int32_t* tri_id
     t.force_pending = 0u;
     t.wave_log = nullptr;
     HIP_TRY(hipEventRecord(s->ev_trace[0][0], nullptr));
-    if (wide) launch_traceq4_cfg(s, trace_cfg4(s, rel4 != nullptr), t, rel4, nullptr);
+    if (wide) launch_traceq4_cfg(s, trace_cfg4(s, rel4 != nullptr), t, rel4, nullptr, nullptr, xs_ctl_of(pp), pp.xs_ring.p);
     else launch_traceq_cfg(s, cfg, t, false, nullptr);
     if (t.steal || wide) {
       TraceQArgs r = t;

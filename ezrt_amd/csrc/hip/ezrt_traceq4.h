@@ -99,7 +99,31 @@ struct TraceQ4Args {
   // cell, direction octant, Morton) is 5-20 % SLOWER than the pipeline's order: mixing cheap and expensive rays in every
   // wave is worth more than coherent memory accesses.  Only the order of processing changes: every ray keeps its slot.
   uint32_t gscat_shift;
+  // Cross-wave work stealing (template parameter XS, knob xsteal; round 5): see "Stealing across waves" below.
+  uint32_t* xs_ctl;            // control words of the scratch set's XS groups, XS_CTL_WORDS each (a 64-byte line of its own per group; zeroed
+                               // per chunk): [0] tail (entries published), [1] head (entries claimed), [2] waves of the group whose queue ran
+                               // dry and that still hold rays, [3] entries a claimer gave up waiting for (must stay 0)
+  unsigned long long* xs_ring; // per group XS_GRING entries of (subtree reference << 32 | ray slot); 0 = empty (zeroed once, re-zeroed by whoever takes an entry)
+  uint32_t xs_gmask;           // groups - 1 (a power of two <= XS_GROUPS_MAX): workgroup b belongs to group b & xs_gmask
+  uint32_t xs_stock;           // entries a group's donors keep published (they stop at this many unclaimed)
+  uint32_t xs_min_idle;        // a wave claims entries only with at least this many idle lanes beyond what its own rich lanes can feed (1 .. 64)
+  // Ray hand-over (knob handover; round 5): once the queue is exhausted, an idle lane takes the PREFETCHED ray of a lane that is still
+  // traversing -- a whole ray that has not started, handed over in registers (shuffles): no split, no atomic, nothing speculative.
+  // Without it the last two rays of a lane (the one it traverses, the one it holds prefetched) run one after the other while the
+  // lanes next to it have nothing to do: "a wave runs on for" 104 us (median) after stage 1's queue is found empty.
+  uint32_t handover;
 };
+constexpr uint32_t XS_CTL_WORDS = 16;   // control words per group: one 64-byte line
+constexpr uint32_t XS_GROUPS_MAX = 512; // groups per launch at most
+constexpr uint32_t XS_GRING_LOG2 = 12, XS_GRING = 1u << XS_GRING_LOG2; // ring entries per group
+// A donor sees its group's ring one iteration late, so unclaimed entries can exceed xs_stock by what the group's waves publish inside that
+// window: at most XS_GIVE_MAX per wave and iteration -- 7 168 waves in >= 16 groups: 448 x 8 = 3 584 < XS_GRING.  (The first version had ONE
+// ring of 65 536 entries and let a wave publish 64 rows at a time: when the queue ran dry every wave did, 393 216 entries, and the claimers
+// spun on overwritten cells for ever.  The second version bounded that and was 30 x SLOWER than no stealing at all: every wave polled ONE
+// control line every iteration, and a line serves ~100 agent-scope reads per microsecond -- an iteration took 100 us.  Hence groups: a
+// control line is polled by the 24-28 waves of its group only.)
+constexpr uint32_t XS_GIVE_MAX = 8;
+constexpr uint32_t XS_BUSY = 2, XS_ERR = 3;
 
 // ---- Distance pruning (PRUNE > 0): results-neutral, proven, not merely observed.
 //
@@ -239,9 +263,35 @@ struct NoPathHook {
 // SEMI: rays with an exactly-zero direction component are traversed here (with the NaN watch) instead of sent to the redo
 // list.  A template parameter because the watch costs every ray of the launch 2-3 % (a ballot per iteration, four flags,
 // registers); the host turns it on for the launches that see such rays in numbers: the MIS integrators' bounce stages.
-template <bool REL, bool LOG, int PRUNE, bool GEN, class Hook, bool SEMI = false, bool GS = false>
+// ---- Stealing across waves (XS; round 5).  A launch used to last as long as its slowest WAVE: the queue runs dry for
+// everybody at about the same time, and from then on a wave can only spread its last rays over its own 64 lanes (the intra-wave
+// stealing above) while the waves that drew cheap rays have retired -- C2's primary stage has its median wave done at 593 us and its
+// last at 749, the 1/8 shard of a frame at 66 and 291.  With XS the pending subtrees cross wave boundaries inside a GROUP of workgroups
+// (workgroup b belongs to group b & xs_gmask: 256 groups of 6-7 workgroups by default) through the group's ring in global memory:
+//  * DONOR: a wave whose queue is exhausted and that has more lanes with pending stack rows than idle lanes of its own publishes
+//    the surplus lanes' OLDEST row (the bottom of the stack: the largest subtree) while fewer than xs_stock of the group's entries
+//    are unclaimed: one atomicAdd on the group's tail reserves the positions, the ray is marked split exactly as for a thief of its
+//    own wave (record reset to "no hit yet", 64-bit atomicMin merges from then on) and its best hit so far is merged at once -- the
+//    thief prunes against it -- then, behind an s_waitcnt, one 8-byte agent-scope store per entry: (reference << 32 | slot), never 0.
+//  * THIEF: a wave with more idle lanes than rich ones claims entries of its group with ONE compare-and-swap on the head (the tail
+//    only grows, so head unchanged means the claimed positions are published or about to be: the entry is polled until it is non-zero,
+//    then zeroed for the ring's next lap).  It reads nothing another wave wrote in this launch except through agent-scope atomics:
+//    the ray comes from the queue the PREVIOUS kernel wrote (or is re-generated: GEN), the bound from the hit record.
+//  * a wave with nothing at all waits for entries of its group (s_sleep between polls) as long as some wave of the group that ran
+//    dry still holds rays (the group's XS_BUSY word); otherwise it retires.
+// No entry is ever lost: a wave only publishes into its own group's ring and only retires after it has SEEN that ring's tail == head
+// later than its own last donation; the head passes a position only by claiming it, and whoever claims an entry traverses it before
+// it retires in turn.  No wave waits for a wave that has not started: waiting depends on a count that only running waves raise, so a
+// grid that is not fully resident (a pipelined chunk's) cannot deadlock; retiring early only loses parallelism.  Every wait is
+// bounded (a protocol error must show as a wrong image and a non-zero XS_ERR word, not as a hung device).  Results: the merge is
+// the minimum of the same triangle set whoever traverses which subtree; pruning against a hit some contributor HAS found is the
+// proven bound (the final minimum is no larger); exact ties between contributors go to the redo list as before.  Visibility
+// (MI355X_MICROARCH.md "inter-workgroup visibility": the XCDs' L2s are not coherent): every word two waves share is only touched
+// by agent-scope atomics.  Polling: a group's control line is read by its own waves only, once per iteration each.
+template <bool REL, bool LOG, int PRUNE, bool GEN, class Hook, bool SEMI = false, bool GS = false, bool XS = false>
 EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
   static_assert(!GEN || REL, "generated rays start at the launch's uniform origin");
+  static_assert(!XS || !Hook::PATH, "a path kernel shades in the refill block: its rays are never split");
   extern __shared__ __attribute__((aligned(16))) int lds_stack[];
   const TraceQArgs& a = A.q;
   // LDS layout: [lane table: BLOCK ints][stack rows][staged records]
@@ -336,12 +386,103 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
       best_t = t;
       best_tri = tri;
       tie_tri = -1; // (a tie at a distance that has just been beaten does not matter any more)
-      if (PRUNE) prune_t = (t + pdelta) * PRUNE_REL;
+      // (XS: a thief's threshold may come from a hit another contributor found, which can be closer than this one)
+      if (PRUNE) prune_t = XS ? hw_min(prune_t, (t + pdelta) * PRUNE_REL) : (t + pdelta) * PRUNE_REL;
     } else if (t == best_t && tri != best_tri) {
       if (A.tri_leaf && tie_tri < 0) tie_tri = tri; // ordered against best_tri at publish (tie_precedes)
       else if (tri != tie_tri) tie = true;           // a third candidate (or no tables): the redo list
     }
   };
+
+  // ---- XS: stealing across waves (see the comment above this function)
+  const bool xs_on = XS && A.xs_ctl != nullptr && a.steal != 0u; // (wave-uniform; the knob is a launch argument)
+  const uint32_t xs_group = XS ? (blockIdx.x & A.xs_gmask) : 0u;
+  uint32_t* const xs_g = A.xs_ctl + (size_t)xs_group * XS_CTL_WORDS;            // this wave's group: control words ...
+  unsigned long long* const xs_gring = A.xs_ring + (size_t)xs_group * XS_GRING; // ... and ring (never touched unless xs_on)
+  unsigned long long xs_seen = 0ull; // the group's control word {tail, head | << 32} as loaded during the previous iteration
+  uint32_t xs_polls = 0u;            // polls of a waiting wave without work
+  bool xs_counted = false;           // this wave is counted in its XS_BUSY word
+  uint32_t dbg_xs_give = 0, dbg_xs_take = 0;
+  auto xs_ctl64 = [&]() { return __hip_atomic_load(reinterpret_cast<unsigned long long*>(xs_g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto xs_adopt = [&](unsigned long long e) { // this lane traverses the published subtree e = (reference << 32 | slot) for that slot's ray
+    slot = (uint32_t)e;
+    float4 vd;
+    if (GEN) vd = primary_dir(A.gen_p, A.gen_blocks, A.gen_div_blocks, A.gen_div_sub, A.gen_scatter, A.gen_scatter_shift, A.gen_frame_first, slot);
+    else vd = a.rq.d[slot]; // (written by the kernel before this one; GEN: the owner's store may still sit in another XCD's L2)
+    if (REL || a.const_origin == 1u) {
+      S = mk(a.origin[0], a.origin[1], a.origin[2]);
+    } else {
+      const float4 vo = a.rq.o[slot >> (a.const_origin >> 1)];
+      S = mk(vo.x, vo.y, vo.z);
+    }
+    d = mk(vd.x, vd.y, vd.z);
+    inv = mk(ez_rcp(d.x), ez_rcp(d.y), ez_rcp(d.z));
+    best_t = INF;
+    best_tri = -1;
+    sp = 0;
+    sb = 0;
+    tie = false;
+    tie_tri = -1;
+    shared = true;
+    semi = SEMI && ray_is_semi(S, d, inv);
+    anyhit = a.anyhit_even != 0u && (slot & 1u) == 0u;
+    ref = (uint32_t)(e >> 32);
+    if (PRUNE) set_delta();
+    // what the ray's other contributors have found so far (the donor merged its best hit before it published the entry): a real
+    // hit of THIS ray, so the final minimum is no larger and the proven margin applies to it
+    const unsigned long long h = __hip_atomic_load(&hits64[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (h != ~0ull) {
+      if (PRUNE) prune_t = hw_min(prune_t, (__uint_as_float((uint32_t)(h >> 32)) + pdelta) * PRUNE_REL);
+      if (anyhit && (int32_t)(uint32_t)h >= 0) finish(); // (an env shadow ray that has hit something is done)
+    }
+  };
+  // claim `want` (>= 1, wave-uniform) published entries for the lanes with taker && trank < want; `head` = the head value the
+  // availability was computed from (tail - head >= want then, and the tail only grows)
+  auto xs_claim = [&](uint32_t head, uint32_t want, bool taker, uint32_t trank) -> bool {
+    uint32_t ok = 0u;
+    if (lane == 0) ok = atomicCAS(xs_g + 1, head, head + want) == head ? 1u : 0u;
+    ok = (uint32_t)__builtin_amdgcn_readfirstlane((int)ok);
+    if (!ok) return false;
+    if (taker && trank < want) {
+      unsigned long long* cell = xs_gring + ((head + trank) & (XS_GRING - 1u));
+      unsigned long long e;
+      uint32_t tries = 0u;
+      do { // (the donor reserved the position before it stored the entry: a store away at most.  Bounded all the same: a
+           // protocol error must show as a wrong image and a non-zero XS_ERR word, not as a hung device)
+        e = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } while (e == 0ull && ++tries < (1u << 18));
+      if (e != 0ull) {
+        __hip_atomic_store(cell, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        xs_adopt(e);
+      } else {
+        atomicAdd(xs_g + XS_ERR, 1u);
+      }
+    }
+    if (LOG && a.wave_log) dbg_xs_take += want;
+    return true;
+  };
+  // publish the oldest pending row of the lanes with donor && drank < n_give (n_give >= 1, wave-uniform)
+  auto xs_donate = [&](uint32_t n_give, bool donor, uint32_t drank) {
+    uint32_t base = 0u;
+    if (lane == 0) base = atomicAdd(xs_g, n_give);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    const bool dn = donor && drank < n_give;
+    int give = 0;
+    if (dn) {
+      give = stack[sb * BLOCK];
+      sb++;
+      if (!shared) atomicExch(&hits64[slot], ~0ull); // first split: "no hit yet"
+      shared = true;
+      if (best_tri >= 0) atomicMin(&hits64[slot], ((unsigned long long)__float_as_uint(best_t) << 32) | (uint32_t)best_tri);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the record is reset (and holds this lane's best) before anybody can see the entry
+    if (dn)
+      __hip_atomic_store(xs_gring + ((base + drank) & (XS_GRING - 1u)), ((unsigned long long)(uint32_t)give << 32) | slot, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    if (LOG && a.wave_log) dbg_xs_give += n_give;
+  };
+  uint32_t* const xs_busy_word = xs_g + XS_BUSY;
+  bool xs_retire = false;
 
   const unsigned long long t_start = (LOG && a.wave_log) ? wall_clock64() : 0ull;
   unsigned long long t_exhausted = 0ull; // (debug_stages=2) when this wave first found the queue empty
@@ -457,21 +598,62 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
         }
       }
     }
-    if (!ballot((ref & nx_slot) != REF_NONE)) break;
+    if (!ballot((ref & nx_slot) != REF_NONE)) {
+      // nobody holds or has prefetched a ray.  That only ends the wave once it has nothing left to DRAW: under the
+      // scattered draw a whole pool can fall into the padding past the queue's end (rs >= n_real) while later static
+      // rounds still hold rays (pool_max 8 with static_pct 50 left 96 of 400 000 rays untraced)
+      if (!exhausted) continue;
+      if (!xs_on) break;
+      // (XS) the steal block below claims subtrees other waves published, waits for some, or retires the wave
+      if (xs_counted) {
+        if (lane == 0) atomicSub(xs_busy_word, 1u);
+        xs_counted = false;
+      }
+    } else if (xs_on && exhausted) {
+      if (!xs_counted) { // from now on this wave may publish: waiting waves stay while any such wave holds rays
+        if (lane == 0) atomicAdd(xs_busy_word, 1u);
+        xs_counted = true;
+      }
+    }
     if (LOG && a.wave_log && exhausted && !t_exhausted) t_exhausted = wall_clock64();
 
     // ---- work stealing: lanes with nothing left to fetch take the oldest pending subtree of a busy lane
     if (a.steal && exhausted) {
+      if (A.handover && !Hook::PATH) { // idle lanes take the prefetched rays of lanes that are still traversing (see TraceQ4Args::handover)
+        const bool idle0 = (ref & nx_slot) == REF_NONE;
+        const bool host = nx_slot != REF_NONE && ref < REF_DONE;
+        const unsigned long long im0 = ballot(idle0), hm = ballot(host);
+        if (im0 && hm) {
+          const int ni0 = (int)__popcll(im0), nh = (int)__popcll(hm);
+          const int n0 = ni0 < nh ? ni0 : nh;
+          const int ir0 = (int)lane_rank(im0), hr = (int)lane_rank(hm);
+          const bool giver = host && hr < n0, taker = idle0 && ir0 < n0;
+          if (giver) wsrc[hr] = lane;
+          __builtin_amdgcn_wave_barrier();
+          const int src = taker ? wsrc[ir0] : lane;
+          const uint32_t hs = (uint32_t)__shfl((int)nx_slot, src, 64);
+          const float hdx = __shfl(nx_d.x, src, 64), hdy = __shfl(nx_d.y, src, 64), hdz = __shfl(nx_d.z, src, 64), hdw = __shfl(nx_d.w, src, 64);
+          float hox = 0.0f, hoy = 0.0f, hoz = 0.0f;
+          if (!REL) hox = __shfl(nx_o.x, src, 64), hoy = __shfl(nx_o.y, src, 64), hoz = __shfl(nx_o.z, src, 64);
+          __builtin_amdgcn_wave_barrier();
+          if (giver) nx_slot = REF_NONE;
+          if (taker) { // (adopted by the next refill, like a ray this lane had prefetched itself)
+            nx_slot = hs;
+            nx_d = make_float4(hdx, hdy, hdz, hdw);
+            if (!REL) nx_o = make_float4(hox, hoy, hoz, 0.0f);
+          }
+        }
+      }
       const bool idle = (ref & nx_slot) == REF_NONE;
       const unsigned long long im = ballot(idle);
-      if (im) {
+      if (im || xs_on) {
         const bool rich = sp > sb;
         const unsigned long long vm = ballot(rich);
-        if (vm) {
+        const int ni = (int)__popcll(im), nv = (int)__popcll(vm);
+        const int n = ni < nv ? ni : nv;
+        const int ir = (int)lane_rank(im), vr = (int)lane_rank(vm);
+        if (n) {
           if (LOG && a.wave_log) dbg_steals++;
-          const int ni = (int)__popcll(im), nv = (int)__popcll(vm);
-          const int n = ni < nv ? ni : nv;
-          const int ir = (int)lane_rank(im), vr = (int)lane_rank(vm);
           const bool victim = rich && vr < n, thief = idle && ir < n;
           int give = 0;
           if (victim) {
@@ -489,6 +671,7 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
                       vsz = REL ? a.origin[2] : __shfl(S.z, src, 64);
           const float vdx = __shfl(d.x, src, 64), vdy = __shfl(d.y, src, 64), vdz = __shfl(d.z, src, 64);
           const int vsemi = __shfl((int)semi, src, 64), vany = __shfl((int)anyhit, src, 64);
+          const float vbt = XS ? __shfl(best_t, src, 64) : INF; // (XS) the victim's best hit so far bounds the thief's pruning too
           if (thief) {
             semi = vsemi != 0;
             anyhit = vany != 0;
@@ -503,10 +686,43 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
             sb = 0;
             ref = (uint32_t)got;
             if (PRUNE) set_delta();
+            if (PRUNE && XS) prune_t = hw_min(prune_t, (vbt + pdelta) * PRUNE_REL);
           }
+        }
+        if (xs_on && ni != nv) { // a surplus of pending rows, or of idle lanes: the business of the group's other waves too
+          const bool all_idle = ni == 64; // (nothing else to do: look at the ring now, not at what the last iteration saw)
+          if (all_idle) xs_seen = xs_ctl64();
+          const uint32_t tail = (uint32_t)xs_seen, head = (uint32_t)(xs_seen >> 32);
+          const int avail = (int)(tail - head);
+          if (nv > ni) {
+            if (avail < (int)A.xs_stock) {
+              int k = nv - ni;
+              const int room = (int)A.xs_stock - avail;
+              k = k < room ? k : room;
+              k = k < (int)XS_GIVE_MAX ? k : (int)XS_GIVE_MAX;
+              xs_donate((uint32_t)k, rich && vr >= n, (uint32_t)(vr - n));
+            }
+          } else if (avail > 0) {
+            // (a claim stalls the whole wave for a few memory round trips -- the head, the entry, the ray, the hit record: worth
+            // it for a wave that is mostly idle, not for one that would fill two lanes and hold up sixty)
+            if (ni - nv >= (int)A.xs_min_idle) {
+              if (!xs_claim(head, (uint32_t)(ni - nv < avail ? ni - nv : avail), idle && ir >= n, (uint32_t)(ir - n)) && all_idle)
+                __builtin_amdgcn_s_sleep(4); // (lost the race for the head)
+              xs_polls = 0u;
+            }
+          } else if (all_idle) {
+            // nothing published and nothing of its own: the wave waits while some wave of its group that ran dry still holds rays
+            // (not for ever), else it retires -- having just SEEN tail == head, later than its own last donation
+            uint32_t b = __hip_atomic_load(xs_busy_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+            if (b == 0u || ++xs_polls > 4096u) xs_retire = true;
+            else __builtin_amdgcn_s_sleep(32);
+          }
+          if (!all_idle && (nv > ni || ni - nv >= (int)A.xs_min_idle)) xs_seen = xs_ctl64(); // (used in the next iteration: nobody waits for it here)
         }
       }
     }
+    if (XS && xs_retire) break;
 
     // ---- inner step: four slab tests (hitAABB, P5/fsh:220-233) on one 4-wide record
     const bool at_inner = (int32_t)ref >= 0;
@@ -766,16 +982,17 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
     w[2] = wave_iters | ((unsigned long long)dbg_inner_steps << 32);
     w[3] = rr | ((unsigned long long)dbg_inner_lanes << 32);
     w[4] = dbg_leaf_lanes | ((unsigned long long)dbg_leaf_rounds << 32);
-    w[5] = dbg_busy_lanes;
+    w[5] = dbg_busy_lanes | ((unsigned long long)(dbg_xs_give & 0xffffu) << 32) | ((unsigned long long)(dbg_xs_take & 0xffffu) << 48);
     w[6] = dbg_refills | ((unsigned long long)dbg_steals << 32);
     w[7] = t_exhausted;
   }
 }
 
 // GS: queue positions are drawn in the scattered order (TraceQ4Args::gscat_shift; granules of 8 slots)
-template <int WPS, bool REL, bool LOG = false, int PRUNE = 0, bool GEN = false, bool SEMI = false, bool GS = false>
+// XS: subtrees are stolen across waves (TraceQ4Args::xs_ctl)
+template <int WPS, bool REL, bool LOG = false, int PRUNE = 0, bool GEN = false, bool SEMI = false, bool GS = false, bool XS = false>
 __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
-  traceq4_body<REL, LOG, PRUNE, GEN, NoPathHook, SEMI, GS>(A, NoPathHook());
+  traceq4_body<REL, LOG, PRUNE, GEN, NoPathHook, SEMI, GS, XS>(A, NoPathHook());
 }
 
 } // namespace ezd

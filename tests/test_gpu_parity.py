@@ -333,6 +333,28 @@ def test_schedule_knobs_never_change_results(hip, bunny_small):
             sg.set_option(k, v)
 
 
+def test_small_pools_with_several_static_rounds_draw_every_ray(hip, bunny_small):
+    """ADVICE r4: under the scattered draw of the bounce stages a whole pool can fall into the padding past the queue's end;
+    a wave whose FIRST pool did used to retire although its later static rounds held rays (pool_max 8, static_pct 50 on
+    a queue of >= 200 000 rays: static_rounds >= 2).  The frame is large enough for that (786 432 pixel-samples in one
+    chunk) and every schedule must give the default's bits."""
+    eye, cam = S.camera(0, 0, 4)
+    for integ, mb in ((50, 3), (51, 2)):
+        p = trace.make_params(512, 512, eye, cam, integ, mb, spp=3)
+        ref = bunny_small.upload(hip).render(p)
+        for opts in ({"bounce_scatter": 1, "pool_max": 8, "pipeline_calls": 0, "static_pct": 50},
+                     {"bounce_scatter": 2, "pool_max": 8, "pipeline_calls": 0, "static_pct": 95},
+                     {"bounce_scatter": 2, "pool_max": 8, "pipeline_calls": 0, "static_pct": 50},
+                     {"bounce_scatter": 1, "pool_div": 8, "pipeline_calls": 0},
+                     {"bounce_scatter": 2, "pool_div": 8, "pipeline_calls": 0, "static_pct": 90},
+                     {"bounce_scatter": 1, "pool_max": 8, "static_pct_pipelined": 50},
+                     {"bounce_scatter": 1, "pool_max": 16, "pipes": 2, "static_pct": 95}):
+            s2 = bunny_small.upload(hip)
+            for k, v in opts.items():
+                s2.set_option(k, v)
+            assert np.array_equal(_bits(s2.render(p)), _bits(ref)), (integ, opts)
+
+
 def test_boxes_that_are_not_nested_fall_back_to_the_binary_kernel(hip, oracle, bunny_small):
     """traceq4_kernel tests descendants without their ancestors, which is only the reference's traversal when
     every box lies inside its parent's (true for the builders' trees).  Caller arrays that violate it -- here
