@@ -54,10 +54,36 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 L2_PEAK_GBS = 34500.0        # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
 LDS_PEAK_GBS = 150000.0      # MI355X_MICROARCH.md "LDS": ~150 TB/s for ds_read_b64/b128 with every CU streaming
-# VALU issue ceiling: tools/exp_valu_issue.hip on this chip (profiles/r2/valu_issue_microbench.txt): wave64 fp32
-# add/mul/mov and the slab test's own opcode mix issue at 1.0-1.09 T wave-instructions/s chip-wide (~2 cycles per
-# instruction per SIMD at the ~2.1-2.4 GHz the chip sustains), fma/min3/cndmask alone at 0.58 T.
+# VALU issue ceiling: tools/exp_valu_issue.hip on this chip: wave64 fp32 add/mul/mov and the slab test's own opcode mix issue at
+# 1.0-1.09 T wave-instructions/s chip-wide (~2 cycles per instruction per SIMD at the ~2.1-2.4 GHz the chip sustains),
+# fma/min3/cndmask alone at 0.58 T.  Read from the round's microbenchmark log (no constant two rounds old): the best
+# row of the fastest opcode (v_mov_b32) = the ceiling `frac` divides by, as in every round; the rate of the timed kernel's own
+# static opcode mix is printed beside it (`peak_kernel_opcode_mix`).  The constants are the fall-back when the log is missing.
 VALU_ISSUE_PEAK_T = 1.086
+VALU_ISSUE_PEAK_KERNEL_MIX_T = None
+VALU_ISSUE_PEAK_SOURCE = "constant (profiles/r2/valu_issue_microbench.txt)"
+
+
+def _read_valu_peak():
+    global VALU_ISSUE_PEAK_T, VALU_ISSUE_PEAK_KERNEL_MIX_T, VALU_ISSUE_PEAK_SOURCE
+    import re
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r5", "valu_issue_microbench.txt")
+    try:
+        rows = open(path).read().splitlines()
+    except OSError:
+        return
+    best = {}
+    for r in rows:
+        m = re.match(r"(.+?)\s+W=(\d+)\s+wall .*? chip ([0-9.]+) T wave-instr/s", r)
+        if m:
+            best[m.group(1).strip()] = max(best.get(m.group(1).strip(), 0.0), float(m.group(3)))
+    if "v_mov_b32" in best:
+        VALU_ISSUE_PEAK_T = best["v_mov_b32"]
+        VALU_ISSUE_PEAK_SOURCE = "profiles/r5/valu_issue_microbench.txt (tools/exp_valu_issue.hip: best v_mov_b32 row)"
+    VALU_ISSUE_PEAK_KERNEL_MIX_T = best.get("traceq4 opcode mix (r5)")
+
+
+_read_valu_peak()
 # ... and the guide's NOMINAL figure for the same ceiling: one wave64 fp32 VALU instruction per 2 cycles per SIMD x 4 SIMDs x
 # 256 CUs x 2.4 GHz (MI355X_MICROARCH.md "Chip-level parameters") = 1.229 T wave-instructions/s.  Both are printed.
 VALU_ISSUE_PEAK_NOMINAL_T = 256 * 4 * 2.4e9 / 2 / 1e12
@@ -277,7 +303,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=("auto", "c2", "c4"), default="auto", help="auto: C2 at 1 GPU, C4 at N > 1")
+    ap.add_argument("--workload", choices=("auto", "c2", "c4"), default="auto", help="auto = c2 for every N (the fixed C2 frame, split N ways at N > 1); c4: BASELINE's C4 instead")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
@@ -434,6 +460,19 @@ def main():
         sc.render_device(p, scratch.data_ptr(), stream)
         step_ms.append(sc.last_render_ms())
     sc.set_option("launch_events", 0)
+    # ... and ONE call at a time without any per-launch event: a call between two synchronisations, nothing to overlap with
+    # (the headline windows queue their steps back to back, so a chunk's late stages run under the next chunk's primary stage:
+    # `value` is that steady-state rate, `value_lone_call` the rate of a host that waits for every frame; VERDICT r4 #5c)
+    lone_ms = []
+    e_l0, e_l1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(9):
+        torch.cuda.synchronize()
+        e_l0.record()
+        sc.render_device(p, scratch.data_ptr(), stream)
+        e_l1.record()
+        torch.cuda.synchronize()
+        lone_ms.append(e_l0.elapsed_time(e_l1))
+    lone_ms_med = statistics.median(lone_ms)
 
     tt = torch.tensor([float(rays_timed)], dtype=torch.float64, device=tdev)
     rank_ms = torch.tensor([statistics.median(m[0] for m in step_ms)], dtype=torch.float64, device=tdev)
@@ -470,6 +509,10 @@ def main():
         "metric": "Mrays/s at fixed spp (Bunny ~70k tris, %s)" % bounce_txt,
         "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "value_lone_call": round(rays_per_step / world / (lone_ms_med * 1e-3) / 1e6, 3) if world == 1 else None,
+        "ms_per_step_lone_call": round(lone_ms_med, 4),
+        "value_note": "value = steps queued back to back (chunks of consecutive calls overlap: pipeline_calls); value_lone_call = one call "
+                      "between two synchronisations, no per-launch events (this rank's shard at N > 1: ms only)",
         "scaling": "n/a" if world == 1 else ("weak" if weak else "strong"),
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s (%d tris, %d BVH nodes, SAH leaf 8), %dx%d, camera rot %g up %g r %g, integrator %d, %d bounces, "
@@ -610,8 +653,12 @@ def main():
                        "peak": VALU_ISSUE_PEAK_T, "unit": "T wave-instr/s", "frac": fr[bound],
                        "peak_measured": VALU_ISSUE_PEAK_T, "peak_nominal": round(VALU_ISSUE_PEAK_NOMINAL_T, 4),
                        "frac_of_nominal_peak": phys["issue_frac_of_nominal_peak"],
-                       "peak_note": "peak = this chip's measured wave64 fp32 issue rate for the slab test's opcode mix "
-                                    "(tools/exp_valu_issue.hip, profiles/r2/valu_issue_microbench.txt); peak_nominal = 256 CUs x 4 SIMDs x "
+                       "peak_kernel_opcode_mix": VALU_ISSUE_PEAK_KERNEL_MIX_T,
+                       "frac_of_kernel_opcode_mix_peak": round(phys["issue_rate_T"] / VALU_ISSUE_PEAK_KERNEL_MIX_T, 4) if VALU_ISSUE_PEAK_KERNEL_MIX_T else None,
+                       "regime": "the dominant kernel ALONE: per-launch events, calls one at a time, chunks not overlapped (pairs with "
+                                 "value_lone_call, not with value)",
+                       "peak_note": "peak = this chip's measured wave64 issue ceiling: " + VALU_ISSUE_PEAK_SOURCE + "; peak_kernel_opcode_mix = the same "
+                                    "microbenchmark on the timed bounce-stage kernel's static opcode histogram; peak_nominal = 256 CUs x 4 SIMDs x "
                                     "2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)",
                        "traffic": phys["traffic_per_launch"], "ceilings": fr, "physical": phys})
             if phys.get("all_kernels_valu_wave_instr_per_step"):

@@ -2336,7 +2336,9 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
     // workgroups become resident only as the other chunk's launches free wave slots, and the pools dealt statically to a
     // workgroup that arrives late are the launch's tail.  With all-dynamic queues for pipelined chunks (static_pct_pipelined
     // = 0) every config gains: C3 +3.0 %, C4 +2.6 %, C5 +1.8 %, C2 unchanged at +13 %.  So every scene is pipelined.
-    const bool xcall = !use_mega && n_pipes == 1 && !s->tune.debug_stages && s->tune.pipeline_calls != 0;
+    // (not with per-launch timing events: they sit on the chunk's stream while the call's begin / end events sit on the caller's, and two
+    // overlapping chunks would have their launch intervals summed twice -- ezrt_last_render_ms describes calls run one chunk at a time)
+    const bool xcall = !use_mega && n_pipes == 1 && !s->tune.debug_stages && s->tune.pipeline_calls != 0 && !s->tune.launch_events;
     const int n_scratch = xcall ? 2 : n_pipes;
     if (!use_mega) { // size the chunk's queues now: if they do not fit, halve the chunk (same results, more launches)
       const bool mis = p->integrator == EZRT_INTEGRATOR_P5_MIS || p->integrator == EZRT_INTEGRATOR_P5_MIS_ANISO;

@@ -221,7 +221,7 @@ int ezrt_mgpu_create(const float* tri, int n_tri, const float* nodes, int n_node
           if (e != hipSuccess) (void)hipGetLastError();                    // (already enabled is fine)
         }
       }
-  if (transport == EZRT_TRANSPORT_RCCL && n_devices > 1) {
+  if (transport == EZRT_TRANSPORT_RCCL) { // (one device too: its gather sends the frame to itself, see ezrt_mgpu_gather)
     m->comms.assign((size_t)n_devices, nullptr);
     int e = g_rccl.CommInitAll(m->comms.data(), n_devices, devices);
     if (e != 0) {
@@ -369,7 +369,38 @@ int ezrt_mgpu_gather(EzrtMgpu* m, float* accum_rgba) {
     MG_TRY(hipEventRecord(q.e_ready, q.st));
   }
   // 2. the shards travel to the root: ONE grouped exchange
-  if (m->transport == EZRT_TRANSPORT_RCCL && n > 1) {
+  if (m->transport == EZRT_TRANSPORT_RCCL && n == 1) {
+    // One device: nothing has to travel, but a host that asked for RCCL gets RCCL -- the frame is packed, sent to ITSELF through
+    // a grouped ncclSend / ncclRecv on the communicator ncclCommInitAll made for the one device, and un-permuted back over the
+    // same pixels (the same bits).  This is what a one-GPU box can exercise of the transport: the library is
+    // found and bound, the communicator exists, a group with a send and a receive completes on the device's stream.
+    const size_t cnt = ezrt_tiles_packed_texels(&plan, 0);
+    if (cnt) {
+      MG_TRY(hipSetDevice(root.dev));
+      if (cnt > root.packed_texels) {
+        if (root.packed) MG_TRY(hipFree(root.packed));
+        root.packed = nullptr;
+        MG_TRY(hipMalloc((void**)&root.packed, cnt * sizeof(float4)));
+        root.packed_texels = cnt;
+      }
+      if (cnt > m->recv_texels) {
+        if (m->recv) MG_TRY(hipFree(m->recv));
+        m->recv = nullptr;
+        MG_TRY(hipMalloc((void**)&m->recv, cnt * sizeof(float4)));
+        m->recv_texels = cnt;
+      }
+      hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, root.st, root.accum, plan, 0, cnt, root.packed);
+      {
+        RcclGroup group;
+        NCCL_TRY(group.start());
+        NCCL_TRY(g_rccl.Send(root.packed, cnt * 4, kNcclFloat, 0, m->comms[0], root.st));
+        NCCL_TRY(g_rccl.Recv(m->recv, cnt * 4, kNcclFloat, 0, m->comms[0], root.st));
+        NCCL_TRY(group.end());
+      }
+      hipLaunchKernelGGL(unpack_tiles_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, root.st, m->recv, plan, 0, cnt, root.accum);
+      total = cnt; // (reported as the gather's payload)
+    }
+  } else if (m->transport == EZRT_TRANSPORT_RCCL && n > 1) {
     RcclGroup group; // (closed by its destructor when a send / receive below fails)
     NCCL_TRY(group.start());
     size_t off = 0;

@@ -174,6 +174,10 @@ int ezrt_counters_reset(EzrtScene* s);
  * milliseconds, measured with hipEvents on the launch stream; total and the
  * trace launches alone -- the latter only with ezrt_set_option(s, "launch_events", 1) set before the call (a pair of
  * events around every trace launch; off by default, each record costs the stream a few microseconds), 0 otherwise.
+ * total_ms is the span between two events on the CALLER's stream around the call.  With launch_events set the call's chunks run
+ * one at a time on that stream (no overlap across chunks or calls), so trace_kernel_ms <= total_ms and both describe the same
+ * serial schedule; without it consecutive chunks and calls overlap (pipeline_calls) and total_ms of a call that was queued
+ * behind another one includes the wait for it.
  * Forces a sync on the events. */
 int ezrt_last_render_ms(EzrtScene* s, float* total_ms, float* trace_kernel_ms, int* n_trace_launches);
 

@@ -314,7 +314,12 @@ def test_schedule_knobs_never_change_results(hip, bunny_small):
                      {"pipeline_calls": 0}, {"pipeline_calls": 0, "chunk_log2": 12}, {"pipeline_calls": 2, "chunk_log2": 12},
                      {"pipeline_calls": 2, "debug_oom_above": 30000}, {"pipeline_calls": 2, "debug_force_pending": 3, "redo_overlap": 1},
                      {"bounce_scatter": 0}, {"bounce_scatter": 2}, {"bounce_scatter": 2, "debug_force_pending": 3}, {"bounce_scatter": 2, "steal": 0},
-                     {"bounce_scatter": 1, "pool_max": 8}, {"bounce_scatter": 2, "static_pct": 0}, {"bounce_scatter": 2, "chunk_log2": 12}):
+                     {"bounce_scatter": 1, "pool_max": 8}, {"bounce_scatter": 2, "static_pct": 0}, {"bounce_scatter": 2, "chunk_log2": 12},
+                     {"handover": 0}, {"handover": 1, "steal": 0}, {"handover": 1, "debug_force_pending": 3},
+                     {"xsteal": 1}, {"xsteal": 1, "xsteal_min_idle": 1, "xsteal_stock": 64}, {"xsteal": 1, "xsteal_groups": 16},
+                     {"xsteal": 1, "debug_force_pending": 3}, {"xsteal": 1, "steal": 0}, {"xsteal": 1, "bounce_scatter": 2},
+                     {"xsteal": 1, "semi": 2}, {"xsteal": 1, "prune": 1}, {"xsteal": 1, "anyhit": 0}, {"xsteal": 1, "debug_stack_cap": 2},
+                     {"xsteal": 1, "gen_primary": 0}, {"xsteal": 1, "pipeline_calls": 0, "trace_wps_rel": 0}):
             s2 = bunny_small.upload(hip)
             for k, v in opts.items():
                 s2.set_option(k, v)
@@ -337,7 +342,8 @@ def test_small_pools_with_several_static_rounds_draw_every_ray(hip, bunny_small)
     """ADVICE r4: under the scattered draw of the bounce stages a whole pool can fall into the padding past the queue's end;
     a wave whose FIRST pool did used to retire although its later static rounds held rays (pool_max 8, static_pct 50 on
     a queue of >= 200 000 rays: static_rounds >= 2).  The frame is large enough for that (786 432 pixel-samples in one
-    chunk) and every schedule must give the default's bits."""
+    chunk) and every schedule must give the default's bits -- also with subtrees stolen across waves (xsteal), which needs
+    launches of this size to publish anything."""
     eye, cam = S.camera(0, 0, 4)
     for integ, mb in ((50, 3), (51, 2)):
         p = trace.make_params(512, 512, eye, cam, integ, mb, spp=3)
@@ -348,7 +354,10 @@ def test_small_pools_with_several_static_rounds_draw_every_ray(hip, bunny_small)
                      {"bounce_scatter": 1, "pool_div": 8, "pipeline_calls": 0},
                      {"bounce_scatter": 2, "pool_div": 8, "pipeline_calls": 0, "static_pct": 90},
                      {"bounce_scatter": 1, "pool_max": 8, "static_pct_pipelined": 50},
-                     {"bounce_scatter": 1, "pool_max": 16, "pipes": 2, "static_pct": 95}):
+                     {"bounce_scatter": 1, "pool_max": 16, "pipes": 2, "static_pct": 95},
+                     # cross-wave stealing (knob xsteal, off by default: measured slower) only does anything in launches of this size
+                     {"xsteal": 1}, {"xsteal": 1, "xsteal_min_idle": 8, "xsteal_stock": 128}, {"xsteal": 1, "pipeline_calls": 0},
+                     {"xsteal": 1, "xsteal_groups": 16, "xsteal_min_idle": 1}, {"handover": 0}):
             s2 = bunny_small.upload(hip)
             for k, v in opts.items():
                 s2.set_option(k, v)

@@ -4,7 +4,10 @@ CPU: the tile index rules (include/ezrt_tiles.h) against tiles.TilePlan, and the
 un-permute sequence through the oracle's implementation of the header (host memory as "devices").  GPU: the product's
 implementation with several shards on the one GPU of the test box (peer and host transports), bit-identical to the
 single-device frame of ezrt_render; RCCL needs distinct devices, so on one GPU only its N = 1 path runs here -- the N > 1
-RCCL exchange is exercised by bench.py --gpus N under torch.distributed (same packed layout, same kernels)."""
+RCCL exchange is exercised by bench.py --gpus N under torch.distributed (same packed layout, same kernels).  What one GPU CAN
+exercise of RCCL is run here (round 5): ezrt_mgpu with EZRT_TRANSPORT_RCCL on one device binds librccl, creates the communicator
+and sends the frame to itself through a grouped ncclSend / ncclRecv; torch.distributed's nccl backend with world_size 1 runs a
+collective and tiles.gather_frame's nccl branch (test_gpu_nccl_backend_world_size_one_*)."""
 import ctypes as C
 
 import numpy as np
@@ -116,6 +119,54 @@ def test_gpu_rccl_transport_rejects_repeated_devices(hip):
         mgpu.Mgpu(hip, bs.tri, bs.nodes, devices=[0, 0], transport="rccl")
     with pytest.raises(trace.TraceError, match="not visible"):
         mgpu.Mgpu(hip, bs.tri, bs.nodes, devices=[0, 99], transport="peer")
+
+
+_NCCL_WORLD_ONE = r"""
+import os, sys, socket
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+from ezrt_amd import scene as S, scenes, trace, tiles
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+assert dist.get_backend() == "nccl"
+t = torch.arange(1024, dtype=torch.float32, device="cuda")
+dist.all_reduce(t)                      # a real RCCL collective: the communicator is created, a kernel runs
+torch.cuda.synchronize()
+assert torch.equal(t.cpu(), torch.arange(1024, dtype=torch.float32))
+hip = trace.hip()
+bs = scenes.bunny_scene(subdiv=0, want_cache=True)
+sc = bs.upload(hip)
+eye, cam = S.camera(0, 0, 4)
+W, H, T = 96, 64, 16
+p = trace.make_params(W, H, eye, cam, 51, 3, spp=3, tile=(T, T), shard=(0, 1))
+want = sc.render(p)
+acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+sc.render_device(p, acc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+plan = tiles.TilePlan(W, H, T, T, 1)
+out = tiles.gather_frame(acc, plan, 0, dist, dst=0, lib=hip.lib)       # the driver's N-GPU code path, nccl branch, one rank
+torch.cuda.synchronize()
+assert np.array_equal(out.cpu().numpy().view(np.uint32), np.asarray(want).view(np.uint32))
+out2 = tiles.gather_frame(acc.clone(), plan, 0, dist, dst=0)            # torch-indexing variant: pack -> dist.gather -> unpack
+torch.cuda.synchronize()
+assert np.array_equal(out2.cpu().numpy().view(np.uint32), np.asarray(want).view(np.uint32))
+dist.barrier()
+dist.destroy_process_group()
+print("NCCL_WORLD_ONE_OK")
+"""
+
+
+@pytest.mark.gpu
+def test_gpu_nccl_backend_world_size_one_runs_a_collective_and_gather_frame():
+    """RCCL has never seen this code on N > 1 GPUs (the environment grants one).  What one GPU allows: the nccl
+    backend initialised with world_size 1, a collective on a device tensor, and tiles.gather_frame through its nccl branch --
+    in a process of its own under a timeout, so that a transport that hangs fails the test instead of the suite."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", _NCCL_WORLD_ONE], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "NCCL_WORLD_ONE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
 @pytest.mark.gpu

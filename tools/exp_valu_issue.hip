@@ -15,9 +15,9 @@
 #include <vector>
 
 #define REP8(x) x x x x x x x x
-enum { OP_ADD, OP_MUL, OP_FMA, OP_MAX, OP_MIN3, OP_CNDMASK, OP_ADDU, OP_PKFMA, OP_RCP, OP_MIX, OP_CND64, OP_CMPCND, OP_ADDCND, OP_MAXE64, OP_MOV, OP_CNDVCC_NOCLOB, OP_CNDVCC_E64, OP_CMPVCC_CND, N_OPS };
+enum { OP_ADD, OP_MUL, OP_FMA, OP_MAX, OP_MIN3, OP_CNDMASK, OP_ADDU, OP_PKFMA, OP_RCP, OP_MIX, OP_CND64, OP_CMPCND, OP_ADDCND, OP_MAXE64, OP_MOV, OP_CNDVCC_NOCLOB, OP_CNDVCC_E64, OP_CMPVCC_CND, OP_KMIX, N_OPS };
 static const char* kNames[N_OPS] = {"v_add_f32", "v_mul_f32", "v_fma_f32", "v_max_f32", "v_min3_f32", "v_cndmask_b32",
-                                    "v_add_u32", "v_pk_fma_f32", "v_rcp_f32", "mix(add,mul,max,min3)", "v_cndmask_b32_e64 s[]", "v_cmp_lt+v_cndmask", "v_add,v_cndmask altern.", "v_max_f32_e64", "v_mov_b32", "v_cndmask_e32 vcc (no clobber)", "v_cndmask_e64 vcc", "v_cmp_e32 vcc + v_cndmask_e32 vcc"};
+                                    "v_add_u32", "v_pk_fma_f32", "v_rcp_f32", "mix(add,mul,max,min3)", "v_cndmask_b32_e64 s[]", "v_cmp_lt+v_cndmask", "v_add,v_cndmask altern.", "v_max_f32_e64", "v_mov_b32", "v_cndmask_e32 vcc (no clobber)", "v_cndmask_e64 vcc", "v_cmp_e32 vcc + v_cndmask_e32 vcc", "traceq4 opcode mix (r5)"};
 
 template <int OP>
 __global__ __launch_bounds__(256) void issue_kernel(int iters, float seed, unsigned long long* cycles, float* sink) {
@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) void issue_kernel(int iters, float seed, unsig
   typedef float v2 __attribute__((ext_vector_type(2)));
   v2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, pk = {k, k};
   unsigned long long msk = 0x5555aaaa3333ccccull ^ (unsigned long long)iters, m0 = 0, m1 = 0;
+  unsigned u0 = threadIdx.x, u1 = threadIdx.x + 1u, u2 = threadIdx.x + 2u, u3 = threadIdx.x + 3u;
   __builtin_amdgcn_s_barrier();
   const unsigned long long r0 = wall_clock64();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -83,6 +84,32 @@ __global__ __launch_bounds__(256) void issue_kernel(int iters, float seed, unsig
       REP8(REP8(asm volatile("v_pk_fma_f32 %0, %0, %4, %4\n\tv_pk_fma_f32 %1, %1, %4, %4\n\tv_pk_fma_f32 %2, %2, %4, %4\n\tv_pk_fma_f32 %3, %3, %4, %4" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pk));
                 asm volatile("v_pk_fma_f32 %0, %0, %4, %4\n\tv_pk_fma_f32 %1, %1, %4, %4\n\tv_pk_fma_f32 %2, %2, %4, %4\n\tv_pk_fma_f32 %3, %3, %4, %4" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pk));))
     }
+    if (OP == OP_KMIX) {
+      // round 5: the STATIC opcode histogram of the timed bounce-stage kernel, traceq4_kernel<6,false,false,2,false,false,true>
+      // (1 028 VALU instructions: v_mov 15 %, v_mul 13 %, v_sub 9 %, compares 10 %, v_cndmask 6 %, v_and 4 %, v_add_f32 4 %, v_add_u32 3 %,
+      // v_lshl_add 4 %, v_fma + v_fmac 5 %, shifts 3 %, v_rcp 1.5 %, v_min3 / v_max3 1 %, the rest singles), as 64 independent
+      // instructions: 32 on a0..a3 / u0..u1, 32 on a4..a7 / u2..u3 (one v_rcp in the second half)
+      REP8(asm volatile(
+               "v_mov_b32 %0, %6\n\tv_mul_f32 %1, %1, %6\n\tv_sub_f32 %2, %2, %6\n\tv_cmp_lt_f32_e32 vcc, %3, %6\n\t"
+               "v_cndmask_b32_e32 %0, %0, %6, vcc\n\tv_and_b32 %4, %4, %5\n\tv_mul_f32 %2, %2, %6\n\tv_mov_b32 %3, %6\n\t"
+               "v_add_f32 %1, %1, %6\n\tv_add_u32 %5, %5, %4\n\tv_mul_f32 %0, %0, %6\n\tv_lshl_add_u32 %4, %4, 1, %5\n\t"
+               "v_fma_f32 %2, %2, %6, %6\n\tv_mov_b32 %3, %6\n\tv_sub_f32 %1, %1, %6\n\tv_cmp_lt_f32_e32 vcc, %0, %6\n\t"
+               "v_cndmask_b32_e32 %3, %3, %6, vcc\n\tv_fmac_f32 %2, %6, %6\n\tv_mul_f32 %1, %1, %6\n\tv_lshlrev_b32 %5, 1, %5\n\t"
+               "v_mov_b32 %0, %6\n\tv_and_b32 %4, %4, %5\n\tv_sub_f32 %3, %3, %6\n\tv_max3_f32 %2, %2, %6, %6\n\t"
+               "v_add_u32 %5, %5, %4\n\tv_mul_f32 %1, %1, %6\n\tv_cmp_lt_f32_e32 vcc, %3, %6\n\tv_xor_b32 %4, %4, %5\n\t"
+               "v_mov_b32 %0, %6\n\tv_lshl_add_u32 %5, %5, 2, %4\n\tv_lshrrev_b32 %4, 1, %4\n\tv_or_b32 %5, %5, %4"
+               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(u0), "+v"(u1) : "v"(k) : "vcc");
+           asm volatile(
+               "v_mov_b32 %0, %6\n\tv_mul_f32 %1, %1, %6\n\tv_sub_f32 %2, %2, %6\n\tv_cmp_lt_f32_e32 vcc, %3, %6\n\t"
+               "v_cndmask_b32_e32 %0, %0, %6, vcc\n\tv_and_b32 %4, %4, %5\n\tv_mul_f32 %2, %2, %6\n\tv_rcp_f32 %3, %3\n\t"
+               "v_add_f32 %1, %1, %6\n\tv_add_u32 %5, %5, %4\n\tv_mul_f32 %0, %0, %6\n\tv_lshl_add_u32 %4, %4, 1, %5\n\t"
+               "v_fma_f32 %2, %2, %6, %6\n\tv_mov_b32 %3, %6\n\tv_sub_f32 %1, %1, %6\n\tv_cmp_lt_f32_e32 vcc, %0, %6\n\t"
+               "v_cndmask_b32_e32 %3, %3, %6, vcc\n\tv_fmac_f32 %2, %6, %6\n\tv_mul_f32 %1, %1, %6\n\tv_lshlrev_b32 %5, 1, %5\n\t"
+               "v_mov_b32 %0, %6\n\tv_and_b32 %4, %4, %5\n\tv_sub_f32 %3, %3, %6\n\tv_min3_f32 %2, %2, %6, %6\n\t"
+               "v_add_u32 %5, %5, %4\n\tv_mul_f32 %1, %1, %6\n\tv_cmp_lt_f32_e32 vcc, %3, %6\n\tv_xor_b32 %4, %4, %5\n\t"
+               "v_mov_b32 %0, %6\n\tv_lshl_add_u32 %5, %5, 2, %4\n\tv_lshrrev_b32 %4, 1, %4\n\tv_or_b32 %5, %5, %4"
+               : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(u2), "+v"(u3) : "v"(k) : "vcc");)
+    }
     if (OP == OP_MIX) { // the slab test's mix
       REP8(REP8(asm volatile("v_sub_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %4\n\tv_max_f32 %2, %2, %4\n\tv_min3_f32 %3, %3, %4, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k));
                 asm volatile("v_sub_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %4\n\tv_min_f32 %2, %2, %4\n\tv_max3_f32 %3, %3, %4, %4" : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k));))
@@ -92,7 +119,7 @@ __global__ __launch_bounds__(256) void issue_kernel(int iters, float seed, unsig
   const unsigned long long r1 = wall_clock64();
   if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
   if (threadIdx.x == 0 && blockIdx.x == 0) { cycles[gridDim.x * 4] = t1 - t0; cycles[gridDim.x * 4 + 1] = r1 - r0; }
-  if (m0 + m1 == 12345ull) sink[1] = 1.0f;
+  if (m0 + m1 == 12345ull || (u0 ^ u1 ^ u2 ^ u3) == 0x12345u) sink[1] = 1.0f;
   float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
   if (s == 123.456f) sink[0] = s;
 }
@@ -133,12 +160,19 @@ void run(int cus) {
   }
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const bool quick = argc > 1 && argv[1][0] == 'q'; // `exp_valu quick`: the rows bench.py reads (ceiling = v_mov, the kernel's mix) + the slab mix
   hipDeviceProp_t prop;
   hipGetDeviceProperties(&prop, 0);
   const int cus = prop.multiProcessorCount;
   printf("device %s, %d CUs, clock %.0f MHz (reported max)\n", prop.gcnArchName, cus, prop.clockRate / 1000.0);
   printf("reading: per-SIMD G wave-instr/s / clock GHz = wave64 instructions per cycle per SIMD (0.5 = 2-cycle issue, 0.25 = 4-cycle)\n");
+  if (quick) {
+    run<OP_MOV>(cus);
+    run<OP_MIX>(cus);
+    run<OP_KMIX>(cus);
+    return 0;
+  }
   run<OP_ADD>(cus);
   run<OP_MUL>(cus);
   run<OP_FMA>(cus);
@@ -157,5 +191,6 @@ int main() {
   run<OP_CNDVCC_NOCLOB>(cus);
   run<OP_CNDVCC_E64>(cus);
   run<OP_CMPVCC_CND>(cus);
+  run<OP_KMIX>(cus);
   return 0;
 }
