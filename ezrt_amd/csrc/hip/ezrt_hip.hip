@@ -158,6 +158,7 @@ struct Tuning {
                            // streams, so that a chunk's latency-bound late stages run under the next chunk's primary stage; only the
                            // accumulation into the caller's frame buffer stays on the caller's stream, in order (ezrt_render_device).
                            // 1 (default; 2 is accepted as the same): every scene; 0: never
+  int pipeline_depth = 0;  // chunks in flight under pipeline_calls: 2 .. 4 scratch sets and streams; 0 (default) = 2 (ezrt_render_device: measured)
   int static_pct_pipelined = 0; // static_pct of the trace launches of a pipelined chunk: its workgroups become resident as the other chunk's
                            // launches free wave slots, and a pool dealt statically to a workgroup that arrives late is the launch's tail.
                            // With the queues all dynamic pipelining gains on every config (C3 +3.0 %, C4 +2.6 %, C5 +1.8 %, C2 +13 %); with
@@ -228,6 +229,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"bounce_scatter", &Tuning::bounce_scatter, 0, 2},
                               {"pipeline_calls", &Tuning::pipeline_calls, 0, 2},
                               {"static_pct_pipelined", &Tuning::static_pct_pipelined, 0, 95},
+                              {"pipeline_depth", &Tuning::pipeline_depth, 0, 4},
                               {"handover", &Tuning::handover, 0, 1},
                               {"xsteal", &Tuning::xsteal, 0, 1},
                               {"xsteal_stock", &Tuning::xsteal_stock, 1, 256},
@@ -324,7 +326,7 @@ struct EzrtScene {
   // Two independent sets of render scratch: a call's frames are cut into sub-chunks that alternate
   // between them, each on its own stream, so one sub-chunk's latency-bound phases (the ends of the
   // persistent trace launches, the late bounces, launch gaps) run under the other's bulk work.
-  Pipe pipe[2];
+  Pipe pipe[ezh::SHARED_STREAMS]; // (two used unless chunks are pipelined deeper: knob pipeline_depth)
   int num_cus = 0;
   uint32_t chunk_seq = 0;     // chunks rendered so far (pipeline_calls: chunk i uses scratch set i & 1)
   bool chunk_pipelined = false; // the chunk being enqueued runs on a scratch set's own stream (set by ezrt_render_device)
@@ -700,12 +702,13 @@ int ensure_events(EzrtScene* s) {
   }
   if (!s->pipe[0].stream) {
     // (the device's shared pair: ezrt_streams.h says why the two streams the chunks alternate between are not the scene's own)
-    hipStream_t pair[2];
+    hipStream_t pair[ezh::SHARED_STREAMS];
     int dev = 0;
     HIP_TRY(ezh::stream_shared_pair(pair, &dev));
-    s->pipe[0].stream = pair[0];
-    s->pipe[1].stream = pair[1];
-    s->pipe[0].stream_device = s->pipe[1].stream_device = dev;
+    for (int i = 0; i < ezh::SHARED_STREAMS; i++) {
+      s->pipe[i].stream = pair[i];
+      s->pipe[i].stream_device = dev;
+    }
   }
   for (Pipe& q : s->pipe) {
     // (the side stream of the redo launches -- knob redo_overlap, off by default -- is taken from the pool when first needed)
@@ -2339,7 +2342,19 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
     // (not with per-launch timing events: they sit on the chunk's stream while the call's begin / end events sit on the caller's, and two
     // overlapping chunks would have their launch intervals summed twice -- ezrt_last_render_ms describes calls run one chunk at a time)
     const bool xcall = !use_mega && n_pipes == 1 && !s->tune.debug_stages && s->tune.pipeline_calls != 0 && !s->tune.launch_events;
-    const int n_scratch = xcall ? 2 : n_pipes;
+    // How many chunks may be in flight (knob pipeline_depth; round 5): 2 scratch sets and streams (default), 3 or 4.
+    // Measured (profiles/r5/pipeline_depth_ab.txt): in a BURST of three calls a third set lets all three overlap -- C2 12.7-12.8 ->
+    // 13.2-13.3 Grays/s, C4 15.55 -> 16.09, C3 7.39 -> 7.68; depth 4 is back at depth 2's rate (a fourth stream shares a hardware queue:
+    // ezrt_streams.h) -- but in steady state (bench.py's windows of 20 steps) depth 3 = depth 2 to four digits (14 943 vs 14 943 Mrays/s):
+    // two chunks in flight already keep the chip as busy as three.  SMALL chunks -- the 1/2, 1/4, 1/8 shards of a C2 frame -- LOSE 3-10 %
+    // at depth 3 or 4 (0.53 -> 0.56-0.59 ms for the eighth: the opposite of VERDICT r4's expectation; every launch of such a chunk is
+    // latency-bound and three half-empty launches contend for the CUs of the same few deep rays).  A third scratch set costs up to 23 GB
+    // (C5 at 2^26 samples in flight), so the default stays 2; 0 = 2.
+    int depth = s->tune.pipeline_depth;
+    if (depth <= 0) depth = 2;
+    if (depth > ezh::SHARED_STREAMS) depth = ezh::SHARED_STREAMS;
+    if (depth < 2) depth = 2;
+    const int n_scratch = xcall ? depth : n_pipes;
     if (!use_mega) { // size the chunk's queues now: if they do not fit, halve the chunk (same results, more launches)
       const bool mis = p->integrator == EZRT_INTEGRATOR_P5_MIS || p->integrator == EZRT_INTEGRATOR_P5_MIS_ANISO;
       for (;;) {
@@ -2360,7 +2375,7 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
     uint32_t k = 0;
     for (uint32_t done = 0; done < p->spp; k++) {
       uint32_t nf = (uint32_t)((p->spp - done < chunk) ? (p->spp - done) : chunk);
-      Pipe& q = s->pipe[xcall ? (s->chunk_seq & 1u) : (n_pipes == 2 ? (k & 1u) : 0u)];
+      Pipe& q = s->pipe[xcall ? (s->chunk_seq % (uint32_t)depth) : (n_pipes == 2 ? (k & 1u) : 0u)];
       hipStream_t qs = (xcall || n_pipes == 2) ? q.stream : st;
       HIP_TRY(q.samples.ensure(per_frame * chunk));
       if (xcall) { // after the accumulation that consumed this scratch set's previous samples (two chunks ago)

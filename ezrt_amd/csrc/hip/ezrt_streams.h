@@ -54,13 +54,15 @@ inline hipError_t stream_acquire(bool high_priority, hipStream_t* out, int* devi
 // alive, 32.2 -> 33.3 with one, -> 31.4 with three, -> 33.4 with three and GPU_MAX_HW_QUEUES=8).  One pair created right after the
 // process's first stream gets two queues of its own and keeps them.  Scenes sharing the pair stay independent: a stream orders the
 // chunks queued to it, nothing in one scene's chunk waits for another scene's.
+// (round 5: the "pair" is SHARED_STREAMS streams -- chunks may be pipelined deeper than two, knob pipeline_depth -- still created together)
+constexpr int SHARED_STREAMS = 4;
 struct SharedPair {
   int device;
-  hipStream_t st[2];
-  int users; // scenes holding the pair (ezrt_trim destroys a pair nobody holds)
+  hipStream_t st[SHARED_STREAMS];
+  int users; // scenes holding the set (ezrt_trim destroys a set nobody holds)
 };
 inline std::vector<SharedPair> g_shared_pairs; // (guarded by g_stream_pool_mu)
-inline hipError_t stream_shared_pair(hipStream_t out[2], int* device) {
+inline hipError_t stream_shared_pair(hipStream_t out[SHARED_STREAMS], int* device) {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
@@ -69,23 +71,21 @@ inline hipError_t stream_shared_pair(hipStream_t out[2], int* device) {
   for (SharedPair& q : g_shared_pairs)
     if (q.device == dev) {
       q.users++;
-      out[0] = q.st[0];
-      out[1] = q.st[1];
+      for (int i = 0; i < SHARED_STREAMS; i++) out[i] = q.st[i];
       return hipSuccess;
     }
   SharedPair q;
   q.device = dev;
   q.users = 1;
-  e = hipStreamCreateWithFlags(&q.st[0], hipStreamNonBlocking);
-  if (e != hipSuccess) return e;
-  e = hipStreamCreateWithFlags(&q.st[1], hipStreamNonBlocking);
-  if (e != hipSuccess) {
-    (void)hipStreamDestroy(q.st[0]);
-    return e;
+  for (int i = 0; i < SHARED_STREAMS; i++) {
+    e = hipStreamCreateWithFlags(&q.st[i], hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      for (int j = 0; j < i; j++) (void)hipStreamDestroy(q.st[j]);
+      return e;
+    }
   }
   g_shared_pairs.push_back(q);
-  out[0] = q.st[0];
-  out[1] = q.st[1];
+  for (int i = 0; i < SHARED_STREAMS; i++) out[i] = q.st[i];
   return hipSuccess;
 }
 
@@ -113,8 +113,7 @@ inline int stream_pool_trim() {
         i++;
         continue;
       }
-      all.push_back({g_shared_pairs[i].device, false, g_shared_pairs[i].st[0]});
-      all.push_back({g_shared_pairs[i].device, false, g_shared_pairs[i].st[1]});
+      for (int k = 0; k < SHARED_STREAMS; k++) all.push_back({g_shared_pairs[i].device, false, g_shared_pairs[i].st[k]});
       g_shared_pairs.erase(g_shared_pairs.begin() + (long)i);
     }
   }

@@ -87,7 +87,9 @@ def test_bench_single_gpu_line_carries_parity_configs_and_model():
         assert c["Mrays_s"] > 0 and c["rays"] > 0 and c["trace_ms"] > 0
         assert c["crop_vs_oracle"]["bit_identical"] is True and c["crop_vs_oracle"]["crop_max"] > 0.05
     rf = out["roofline"]
-    assert rf["peak_measured"] == 1.086 and abs(rf["peak_nominal"] - 1.2288) < 1e-3
+    # (the measured ceiling is read from the round's microbenchmark log, profiles/r5/valu_issue_microbench.txt; 1.086 is the fall-back)
+    assert 0.9 < rf["peak_measured"] < 1.2 and abs(rf["peak_nominal"] - 1.2288) < 1e-3
+    assert out["value_lone_call"] > 0 and out["ms_per_step_lone_call"] > 0   # the un-pipelined rate beside the headline (VERDICT r4 #5c)
     for k in ("C2", "C4"):
         sh = out["scaling_model"][k]["shards"]
         assert set(sh) == {"2", "4", "8"} and all(v["predicted_speedup"] > 0 for v in sh.values())
