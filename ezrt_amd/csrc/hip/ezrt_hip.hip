@@ -165,6 +165,7 @@ struct Tuning {
                            // the unpipelined optimum of 50 it lost 1-5 % on C3 / C4 / C5 (profiles/r4/pipeline_calls_ab.txt)
   int handover = 1;        // traceq4_kernel: once the queue is exhausted, idle lanes take the prefetched (unstarted) rays of lanes of their wave that
                            // are still traversing (TraceQ4Args::handover)
+  int steal_bound = 1;     // traceq4_kernel: a lane that takes a pending subtree of another lane's ray prunes against that lane's best hit so far
   int xsteal = 0;          // (MEASURED SLOWER, see DESIGN.md section 5 "Round 5": default off) traceq4_kernel steals pending subtrees ACROSS waves, inside groups of workgroups, through rings in global memory
                            // (ezrt_traceq4.h "Stealing across waves"; the launches that prune with the nearest-first order, i.e. the default
                            // schedule); 0: within a wave only
@@ -231,6 +232,7 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"static_pct_pipelined", &Tuning::static_pct_pipelined, 0, 95},
                               {"pipeline_depth", &Tuning::pipeline_depth, 0, 4},
                               {"handover", &Tuning::handover, 0, 1},
+                              {"steal_bound", &Tuning::steal_bound, 0, 1},
                               {"xsteal", &Tuning::xsteal, 0, 1},
                               {"xsteal_stock", &Tuning::xsteal_stock, 1, 256},
                               {"xsteal_groups", &Tuning::xsteal_groups, 16, 512},
@@ -973,6 +975,7 @@ void fill_traceq4_args(const EzrtScene* s, const TraceCfg& c4, const TraceQArgs&
   A.xs_gmask = xs_groups(s) - 1u;
   A.xs_min_idle = (uint32_t)s->tune.xsteal_min_idle;
   A.handover = (s->tune.handover && t.steal) ? 1u : 0u;
+  A.steal_bound = s->tune.steal_bound ? 1u : 0u;
 }
 // xs_ctl / xs_ring (or NULL): this launch's control words and the scratch set's ring of published subtrees (knob xsteal)
 void launch_traceq4_cfg(EzrtScene* s, const TraceCfg& c4, const TraceQArgs& t, const float4* rel, hipStream_t st, const WfArgs* gen = nullptr,

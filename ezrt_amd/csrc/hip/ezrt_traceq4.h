@@ -112,6 +112,7 @@ struct TraceQ4Args {
   // Without it the last two rays of a lane (the one it traverses, the one it holds prefetched) run one after the other while the
   // lanes next to it have nothing to do: "a wave runs on for" 104 us (median) after stage 1's queue is found empty.
   uint32_t handover;
+  uint32_t steal_bound;        // a thief (of its own wave) prunes against the victim's best hit so far
 };
 constexpr uint32_t XS_CTL_WORDS = 16;   // control words per group: one 64-byte line
 constexpr uint32_t XS_GROUPS_MAX = 512; // groups per launch at most
@@ -386,8 +387,8 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
       best_t = t;
       best_tri = tri;
       tie_tri = -1; // (a tie at a distance that has just been beaten does not matter any more)
-      // (XS: a thief's threshold may come from a hit another contributor found, which can be closer than this one)
-      if (PRUNE) prune_t = XS ? hw_min(prune_t, (t + pdelta) * PRUNE_REL) : (t + pdelta) * PRUNE_REL;
+      // (a thief's threshold may come from a hit another contributor of its ray found, which can be closer than this one)
+      if (PRUNE) prune_t = hw_min(prune_t, (t + pdelta) * PRUNE_REL);
     } else if (t == best_t && tri != best_tri) {
       if (A.tri_leaf && tie_tri < 0) tie_tri = tri; // ordered against best_tri at publish (tie_precedes)
       else if (tri != tie_tri) tie = true;           // a third candidate (or no tables): the redo list
@@ -671,7 +672,10 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
                       vsz = REL ? a.origin[2] : __shfl(S.z, src, 64);
           const float vdx = __shfl(d.x, src, 64), vdy = __shfl(d.y, src, 64), vdz = __shfl(d.z, src, 64);
           const int vsemi = __shfl((int)semi, src, 64), vany = __shfl((int)anyhit, src, 64);
-          const float vbt = XS ? __shfl(best_t, src, 64) : INF; // (XS) the victim's best hit so far bounds the thief's pruning too
+          // the victim's best hit so far bounds the thief's pruning too (knob steal_bound; round 5): a real hit of the SAME ray, so the
+          // final minimum is no larger and the proven margin applies -- the oldest pending row is the farthest subtree under the
+          // nearest-first order, the one most likely to lie wholly behind that hit, and the thief used to walk it with best_t = INF
+          const float vbt = (PRUNE && A.steal_bound) ? __shfl(best_t, src, 64) : INF;
           if (thief) {
             semi = vsemi != 0;
             anyhit = vany != 0;
@@ -686,7 +690,7 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
             sb = 0;
             ref = (uint32_t)got;
             if (PRUNE) set_delta();
-            if (PRUNE && XS) prune_t = hw_min(prune_t, (vbt + pdelta) * PRUNE_REL);
+            if (PRUNE) prune_t = hw_min(prune_t, (vbt + pdelta) * PRUNE_REL);
           }
         }
         if (xs_on && ni != nv) { // a surplus of pending rows, or of idle lanes: the business of the group's other waves too

@@ -2,7 +2,7 @@
 # tools/gpu_final.sh [ROUND]: the round's kept evidence in one call -- the GPU test suite, the driver's bench command (with the
 # per-config timings and the scaling model), kernel stats + PMC passes of the bench command (tools/profile.sh), the 2- and 8-rank
 # bench lines over gloo on one GPU.  Everything lands under gpurun_out/final/ and is copied to profiles/<ROUND>/ by hand.
-RND=${1:-r4}
+RND=${1:-r5}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/final; mkdir -p $O; cd $R
 (time python -m pytest tests -m gpu -x -q) > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_n1_before_profile.json 2> $O/bench_n1.err

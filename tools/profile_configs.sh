@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/profile_configs.sh [CFG ...]: rocprofv3 evidence for BASELINE configs[2..4] at their stated spp (VERDICT r3 #1c) -- one
 # --kernel-trace --stats run and four --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a pass) (each its own run, --kernel-trace only) of tools/config_one.py per config;
-# tools/summarize_config_profile.py turns them into profiles/r4/<cfg>_kernel_stats.csv and <cfg>_pmc_summary.json.
+# tools/summarize_config_profile.py turns them into profiles/r5/<cfg>_kernel_stats.csv and <cfg>_pmc_summary.json.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 CFGS=${@:-C3 C4 C5}
 declare -A SPP=([C2]=64 [C3]=128 [C4]=256 [C5]=512)
@@ -25,7 +25,7 @@ for c in $CFGS; do
     timeout 150 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $O/pmc$i -o p -- $CMD > $O/pmc$i.log 2>&1 || echo "$c: pmc pass $i failed: $PMC"
   done
   grep -h "Mrays/s" $O/stats.log | tail -1
-  python3 $R/tools/summarize_config_profile.py $c $O $R/gpurun_out/profcfg_summary
+  python3 $R/tools/summarize_config_profile.py $c $O $R/gpurun_out/profcfg_summary ${SPP[$c]} ${SPP_PMC[$c]}
   du -sh $O | tail -1
   rm -rf $O   # (raw traces stay on the box: only the summaries travel back)
 done

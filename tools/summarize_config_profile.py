@@ -24,6 +24,9 @@ def short(name):
 
 def main():
     cfg, src, dst = sys.argv[1], sys.argv[2], sys.argv[3]
+    # (round 5) the spp of the kernel-trace pass and of the counter passes, so that a reader need not redo the ratio
+    spp_trace = int(sys.argv[4]) if len(sys.argv) > 4 else None
+    spp_pmc = int(sys.argv[5]) if len(sys.argv) > 5 else None
     os.makedirs(dst, exist_ok=True)
     stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
     dur = {}
@@ -75,10 +78,28 @@ def main():
             e["l1_accesses"] = int(c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0))
         kernels[k] = e
     trace_share = sum(v["share_of_gpu_time"] or 0 for k, v in kernels.items() if k.startswith("traceq"))
+    # HBM bytes of ALL kernels per pixel-sample (VERDICT r4 #3 asks for this figure): the counter pass renders tools/config_one.py's five
+    # calls (1 warm-up + 3 timed + 1 with launch events) of W x H x spp_pmc pixel-samples each
+    per_sample = None
+    if spp_pmc:
+        from ezrt_amd import scenes
+        c0 = scenes.CONFIGS[cfg]
+        samples = 5.0 * c0["width"] * c0["height"] * spp_pmc
+        tot_hbm = 0.0
+        by_kernel = {}
+        for k, e in kernels.items():
+            n_disp = len(agg.get(k, {}).get("FETCH_SIZE", []))
+            if "hbm_bytes_per_dispatch_in_counter_pass" in e and n_disp:
+                by_kernel[k] = round(e["hbm_bytes_per_dispatch_in_counter_pass"] * n_disp / samples, 1)
+                tot_hbm += e["hbm_bytes_per_dispatch_in_counter_pass"] * n_disp
+        per_sample = {"all_kernels": round(tot_hbm / samples, 1), "by_kernel": {k: v for k, v in by_kernel.items() if v >= 1.0}}
     out = {"config": cfg, "command": "EZRT_PIPELINE_CALLS=0 tools/config_one.py %s at the BASELINE spp (tools/profile_configs.sh): chunks NOT overlapped, every kernel measured alone" % cfg, "source_sha": gpu_source_hash(),
            "note": "kernel times and shares: rocprofv3 --kernel-trace --stats of the config at its BASELINE spp; counters: separate --pmc passes at one "
                    "chunk's worth of frames (same kernels, per-dispatch work smaller by the spp ratio for the per-chunk stages) -- the issue rate of a "
                    "kernel is its counters' VALU instructions / its average duration IN THE SAME pass",
+           "spp_kernel_trace_pass": spp_trace, "spp_counter_passes": spp_pmc,
+           "per_dispatch_scale_counter_pass_over_kernel_trace_pass": round(spp_pmc / float(spp_trace), 4) if (spp_trace and spp_pmc) else None,
+           "hbm_bytes_per_pixel_sample": per_sample,
            "gpu_time_ms_all_ezd_kernels": round(total / 1e6, 3), "trace_kernels_share_of_gpu_time": round(trace_share, 4),
            "hbm_correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md: gfx950 FETCH_SIZE tallies 128-B requests at 64 B)",
            "kernels": kernels}

@@ -105,7 +105,7 @@ def main():
         per_step["hbm_bytes"] = (2.0 * per_step.get("FETCH_SIZE", 0.0) + per_step.get("WRITE_SIZE", 0.0)) * 1024.0
         per_step["l2_bytes"] = per_step.get("TCP_TCC_READ_REQ_sum", 0.0) * 64.0
         per_step["lds_bytes"] = per_step.get("SQ_INSTS_LDS", 0.0) * 64.0 * 16.0
-        summary = {"source_sha": out["source_sha"], "source": dst + "_pmc.json", "dominant": per_step, "all_kernels": all_kernels_per_step(out["kernels"]),
+        summary = {"source_sha": out["source_sha"], "source": os.path.basename(dst) + "_pmc.json", "dominant": per_step, "all_kernels": all_kernels_per_step(out["kernels"]),
                    "note": "per-step sums over the dominant kernel's launches (1 + max_bounce per step); see tools/summarize_profile.py"}
         json.dump(summary, open(os.path.join(os.path.dirname(os.path.abspath(dst)), "pmc_summary.json"), "w"), indent=1)
         print("dominant", dom, "per step: VALU %.4g SALU %.4g HBM %.4g B L2 %.4g B" % (
