@@ -154,10 +154,11 @@ def physical_roofline(trace_ms_per_step, launches_per_step):
     return out, None
 
 
-# crops of the timed full-spp frames that the CPU oracle re-renders (x0, y0, x1, y1), sized so that the oracle needs a few
-# seconds each at the full spp: C3 = the crop of tests/test_gpu_configs.py (1 863 distinct primary triangles over two spheres),
-# C4 / C5 = the 64x48 / 32x24 block of the frame with the most distinct primary triangles (691 on the Bunny / 745 on a sphere)
-CONFIG_CROPS = {"C3": (480, 380, 544, 428), "C4": (448, 288, 512, 336), "C5": (1024, 1128, 1056, 1152)}
+# crops of the timed full-spp frames that the CPU oracle re-renders (x0, y0, x1, y1).  Round 5 ("the driver-line crop
+# checks are small"): sixteen times the pixels of round 4's crops, around the same centres -- C3 256x192 over the sphere grid (round 4: the
+# 64x48 of tests/test_gpu_configs.py), C4 256x192 over the Bunny, its mirror floor and sky, C5 128x96 across spheres, floor tiles and the
+# horizon -- still a few seconds of oracle time each at the full 128 / 256 / 512 spp on the box's 16 cores.
+CONFIG_CROPS = {"C3": (384, 308, 640, 500), "C4": (352, 216, 608, 408), "C5": (976, 1092, 1104, 1188)}
 
 
 def load_oracle():
