@@ -57,6 +57,7 @@ TRACE_ABI = {
     "ezrt_frame_read": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_float_p]),
     "ezrt_frame_write": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_float_p]),
     "ezrt_render_paths": (C.c_int, [C.c_void_p, C.POINTER(EzrtRenderParams), c_int32_p, c_float_p, c_float_p]),
+    "ezrt_frame_nonfinite": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_int64_p]),
     "ezrt_query_hits": (C.c_int, [C.c_void_p, c_float_p, C.c_int, c_int32_p, c_float_p]),
     "ezrt_tonemap": (C.c_int, [c_float_p, C.c_int, c_uint8_p]),
     "ezrt_sobol": (C.c_int, [C.c_uint32, C.c_int, C.c_int, c_float_p]),

@@ -21,7 +21,6 @@
 #include "ezrt.h"
 #include "ezrt_kernels.h"
 #include "ezrt_wavefront.h"
-#include "ezrt_tracepk.h"
 #include "ezrt_traceq4.h"
 #include "ezrt_streams.h"
 
@@ -70,8 +69,6 @@ constexpr int MAX_TRACE_EVENTS = 2048; // launch_events: pairs of timing events 
 // environment variable EZRT_<NAME> overrides the default at scene creation, ezrt_set_option at run time.
 struct Tuning {
   int megakernel = 0;      // 1: v1 one-lane-per-path kernel instead of the streaming pipeline
-  int packet = 0;          // 1: packet traversal for primary rays (slower on C2: 1.48+0.61 ms vs 1.55 ms)
-  int packet_budget = 48;  // steps after which a packet hands its rays to the per-lane kernel
   int leaf_threshold = 12; // lanes waiting at a leaf that trigger the triangle phase (24 until the traversal pruned: 12 is +3 % on C3 / C5 now)
   int pool_div = 1;        // ray-index pool = clamp(n_rays / (n_waves * pool_div), 8, pool_max)
   int pool_min = 8;        // fewest rays a wave is dealt (clamped to pool_max): a short queue then goes to fewer, fuller waves
@@ -82,33 +79,17 @@ struct Tuning {
                            // scratch) and fewer tree records in LDS, still +3.6 % over 5 since the loop got leaner
   int lds_nodes = 1 << 20; // cap on top-of-tree records staged in LDS
   int scatter = 1;         // primary rays enter the queue in a scattered 8x8 sub-block order (balances pools)
-  int pipes = 1;           // 2: sub-chunks of a call alternate between two scratch sets on two streams (measured:
-                           // the kernels do overlap, but each slows the other down and every stage's latency-bound
-                           // end is paid twice: 3.81 vs 3.65 ms per C2 frame)
-  int sub_frames = 0;      // frames per sub-chunk when pipelined (0: half the call's frames)
   int static_pct = 50;     // share of a trace queue dealt statically to the waves, percent (0: one pool each)
   int refill_min = 24;     // free lanes a wave waits for before it runs its refill code (publish results, adopt the
                            // prefetched ray, prefetch the next): wave-wide code for per-lane events, so batch it (+9 %)
   int lazy_dir = 1;        // the primary stage's first shading pass reads a ray's direction only after its hit record said "miss"
   int refill_min_rel = 40; // ... of the primary stage's launch (rays with a common origin; 0: refill_min): its refill also generates the rays
                            // (C2 +1.8 %, C4 +3.1 %, C3 / C5 +0.3 % over 24)
-  int split_shade = 3;     // leaving paths and surface interactions shaded by two kernels: 1 from bounce 1 on, 2 always,
-                           // 3 for the primary stage and bounce 1 only (the small late stages run the fused kernel: one
-                           // launch less each, +0.6 %)
   int rel_boxes = 1;       // primary rays traverse boxes already translated by the eye
   int steal = 1;           // intra-wave work stealing in traceq_kernel (+ a redo launch for exact ties)
   int wide4 = 1;           // traceq4_kernel (4-wide collapse of the tree, ezrt_traceq4.h) for the timed stages; 0: the
                            // binary traceq_kernel.  Instrumented runs (level 1) and scenes whose boxes are not
                            // nested always use the binary kernel.
-  int path_stage = 0;      // from this stage on (>= 2; 0: never -- the default) the surviving paths of a chunk finish in ONE launch of
-                           // pathq4_kernel (integrators without MIS, 4-wide records): a lane keeps its path and is shaded in the
-                           // refill block.  MEASURED SLOWER on C2: stages 2-4 take 450 us staged, 800-1000 us fused (2.59-2.93 vs
-                           // 2.18 ms per step; path_refill_min 56 is the best setting): the longest PATH is about the sum of the stages'
-                           // deepest rays (the same paths stay deep), and every shading batch stalls its wave's live traversals
-                           // for the ~10 us of its dependent loads at 4 waves per SIMD.  Kept as a tested knob.
-  int path_refill_min = 0; // refill_min of that launch (0: the trace launches' value)
-  int tail_stage = 0;      // from this stage on (>= 2; 0: never -- the default: measured 1.95 ms vs 0.43 ms for stages 2-4 of C2) the surviving paths finish in tail_kernel, one lane per
-                           // path, instead of one trace + shading stage per bounce (ezrt_wavefront.h)
   int debug_stages = 0;    // print per-stage queue sizes (synchronises)
   int redo_overlap = 0;    // 1: the redo launch of a stage (exact ties beyond two candidates, rays that are not tame, stack overflows) runs on a
                            // side stream under the stage's first shading pass and the second pass waits for it; 0 (default since round 3):
@@ -153,12 +134,11 @@ struct Tuning {
   int debug_stack_cap = 0; // test hook (prune 2): > 0 = stack rows beyond which a ray goes to the redo list, instead of the scene's bound
   int bounce_scatter = 1;  // the bounce stages' trace launches draw their queue in a scattered order, in granules of 8 rays
                            // (TraceQ4Args::gscat_shift; 0: consecutive slots, the order the shading stage wrote; 1: queues with one
-                           // ray per path; 2: the MIS integrators' two-ray queues too -- measured slower there)
+                           // ray per path.  The MIS integrators' two-ray queues lost 1.3-2.8 % with it: never scattered)
   int pipeline_calls = 1;  // consecutive chunks -- of one call or of consecutive calls -- alternate between the two scratch sets and their own
                            // streams, so that a chunk's latency-bound late stages run under the next chunk's primary stage; only the
                            // accumulation into the caller's frame buffer stays on the caller's stream, in order (ezrt_render_device).
                            // 1 (default; 2 is accepted as the same): every scene; 0: never
-  int pipeline_depth = 0;  // chunks in flight under pipeline_calls: 2 .. 4 scratch sets and streams; 0 (default) = 2 (ezrt_render_device: measured)
   int static_pct_pipelined = 0; // static_pct of the trace launches of a pipelined chunk: its workgroups become resident as the other chunk's
                            // launches free wave slots, and a pool dealt statically to a workgroup that arrives late is the launch's tail.
                            // With the queues all dynamic pipelining gains on every config (C3 +3.0 %, C4 +2.6 %, C5 +1.8 %, C2 +13 %); with
@@ -166,12 +146,6 @@ struct Tuning {
   int handover = 1;        // traceq4_kernel: once the queue is exhausted, idle lanes take the prefetched (unstarted) rays of lanes of their wave that
                            // are still traversing (TraceQ4Args::handover)
   int steal_bound = 1;     // traceq4_kernel: a lane that takes a pending subtree of another lane's ray prunes against that lane's best hit so far
-  int xsteal = 0;          // (MEASURED SLOWER, see DESIGN.md section 5 "Round 5": default off) traceq4_kernel steals pending subtrees ACROSS waves, inside groups of workgroups, through rings in global memory
-                           // (ezrt_traceq4.h "Stealing across waves"; the launches that prune with the nearest-first order, i.e. the default
-                           // schedule); 0: within a wave only
-  int xsteal_stock = 16;   // ... entries a group's donors keep published
-  int xsteal_min_idle = 40; // ... idle lanes (beyond what the wave's own pending rows can feed) from which a wave claims published entries
-  int xsteal_groups = 256; // ... groups per launch (a power of two, 16 .. 512: workgroup b belongs to group b mod groups)
   int audit_via_queue = 0; // 1: ezrt_query_hits and ezrt_render_paths run through the TIMED kernels (traceq_kernel with
                            // the template, LDS layout, stealing and redo launch of a render call + the streaming shading
                            // stages) instead of the in-order audit kernels; 2 (query only): additionally treat the rays as
@@ -183,8 +157,6 @@ struct TuningName {
   int lo, hi; // accepted range (ezrt_set_option rejects anything else; environment overrides are clamped)
 };
 const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
-                              {"packet", &Tuning::packet, 0, 1},
-                              {"packet_budget", &Tuning::packet_budget, 1, 1 << 20},
                               {"leaf_threshold", &Tuning::leaf_threshold, 1, 64},
                               {"pool_div", &Tuning::pool_div, 1, 1 << 16},
                               {"pool_max", &Tuning::pool_max, 8, 4096},
@@ -194,18 +166,12 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"lds_nodes", &Tuning::lds_nodes, 0, 1 << 24},
                               {"steal", &Tuning::steal, 0, 1},
                               {"rel_boxes", &Tuning::rel_boxes, 0, 1},
-                              {"split_shade", &Tuning::split_shade, 0, 3},
                               {"refill_min", &Tuning::refill_min, 1, 64},
                               {"refill_min_rel", &Tuning::refill_min_rel, 0, 64},
                               {"lazy_dir", &Tuning::lazy_dir, 0, 1},
                               {"static_pct", &Tuning::static_pct, 0, 95},
-                              {"pipes", &Tuning::pipes, 1, 2},
-                              {"sub_frames", &Tuning::sub_frames, 0, 1 << 20},
                               {"scatter", &Tuning::scatter, 0, 8},
                               {"wide4", &Tuning::wide4, 0, 1},
-                              {"tail_stage", &Tuning::tail_stage, 0, 64},
-                              {"path_stage", &Tuning::path_stage, 0, 64},
-                              {"path_refill_min", &Tuning::path_refill_min, 0, 64},
                               {"debug_stages", &Tuning::debug_stages, 0, 2},
                               {"env_rgbe", &Tuning::env_rgbe, 0, 1},
                               {"env_planes", &Tuning::env_planes, 0, 1},
@@ -227,16 +193,11 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"prune_min_records", &Tuning::prune_min_records, 0, 1 << 24},
                               {"stack_cap", &Tuning::stack_cap, 0, 64},
                               {"debug_stack_cap", &Tuning::debug_stack_cap, 0, 64},
-                              {"bounce_scatter", &Tuning::bounce_scatter, 0, 2},
+                              {"bounce_scatter", &Tuning::bounce_scatter, 0, 1},
                               {"pipeline_calls", &Tuning::pipeline_calls, 0, 2},
                               {"static_pct_pipelined", &Tuning::static_pct_pipelined, 0, 95},
-                              {"pipeline_depth", &Tuning::pipeline_depth, 0, 4},
                               {"handover", &Tuning::handover, 0, 1},
                               {"steal_bound", &Tuning::steal_bound, 0, 1},
-                              {"xsteal", &Tuning::xsteal, 0, 1},
-                              {"xsteal_stock", &Tuning::xsteal_stock, 1, 256},
-                              {"xsteal_groups", &Tuning::xsteal_groups, 16, 512},
-                              {"xsteal_min_idle", &Tuning::xsteal_min_idle, 1, 64},
                               {"audit_via_queue", &Tuning::audit_via_queue, 0, 2}};
 Tuning tuning_from_env() {
   Tuning t;
@@ -266,9 +227,7 @@ struct Pipe {
   DevBuf<uint32_t> qcounts; // [0..63] path counts per stage, [64..99] trace queue heads, [100..115] debug,
                             // [120] redo count, [121] redo queue head
   DevBuf<uint32_t> redo_slots;
-  DevBuf<uint32_t> qheads;      // traceq reservation counters: [launch slot][TRACE_HEADS][TRACE_HEAD_STRIDE], then the control words of
-                                // cross-wave stealing: [group][XS_CTL_WORDS] (QHEADS_WORDS in all; zeroed per chunk)
-  DevBuf<unsigned long long> xs_ring; // cross-wave stealing: published subtrees, [group][XS_GRING] (all zero between launches)
+  DevBuf<uint32_t> qheads;      // traceq reservation counters: [launch slot][TRACE_HEADS][TRACE_HEAD_STRIDE] (QHEADS_WORDS in all; zeroed per chunk)
   DevBuf<float4> inner_rel;     // inner records translated by -eye (primary rays)
   DevBuf<float4> inner4_rel;    // 4-wide records translated by -eye
   DevBuf<uint4> defer_list;     // split shading: paths with a surface interaction, per workgroup
@@ -328,7 +287,7 @@ struct EzrtScene {
   // Two independent sets of render scratch: a call's frames are cut into sub-chunks that alternate
   // between them, each on its own stream, so one sub-chunk's latency-bound phases (the ends of the
   // persistent trace launches, the late bounces, launch gaps) run under the other's bulk work.
-  Pipe pipe[ezh::SHARED_STREAMS]; // (two used unless chunks are pipelined deeper: knob pipeline_depth)
+  Pipe pipe[ezh::SHARED_STREAMS]; // (two: deeper pipelines were measured in round 5 and removed in round 6)
   int num_cus = 0;
   uint32_t chunk_seq = 0;     // chunks rendered so far (pipeline_calls: chunk i uses scratch set i & 1)
   bool chunk_pipelined = false; // the chunk being enqueued runs on a scratch set's own stream (set by ezrt_render_device)
@@ -772,12 +731,9 @@ TraceCfg trace_cfg(const EzrtScene* s) { // needs s->num_cus
 // the template instance a render call uses for this scene's settings
 void launch_traceq_cfg(EzrtScene* s, const TraceCfg& c, const TraceQArgs& q, bool small, hipStream_t st) {
   const unsigned trace_grid = small ? 64u : c.grid_full; // redo lists are (nearly) empty
-  const int trace_wps = s->tune.trace_wps;
+  // (one register budget since round 6: 6 waves per SIMD = 80 VGPRs; knob trace_wps only sets the workgroups per CU)
   if (s->instr > 0) hipLaunchKernelGGL((traceq_kernel<true, 6>), dim3(trace_grid), dim3(BLOCK), c.lds_t, st, q);
-  else if (trace_wps == 8) hipLaunchKernelGGL((traceq_kernel<false, 8>), dim3(trace_grid), dim3(BLOCK), c.lds_t, st, q);
-  else if (trace_wps == 6) hipLaunchKernelGGL((traceq_kernel<false, 6>), dim3(trace_grid), dim3(BLOCK), c.lds_t, st, q);
-  else if (trace_wps == 4) hipLaunchKernelGGL((traceq_kernel<false, 4>), dim3(trace_grid), dim3(BLOCK), c.lds_t, st, q);
-  else hipLaunchKernelGGL((traceq_kernel<false, 5>), dim3(trace_grid), dim3(BLOCK), c.lds_t, st, q);
+  else hipLaunchKernelGGL((traceq_kernel<false, 6>), dim3(trace_grid), dim3(BLOCK), c.lds_t, st, q);
   s->n_trace_launches++;
 }
 // the same for traceq4_kernel: fewer stack rows (stack_need4), 112-B records in LDS
@@ -799,12 +755,6 @@ int stack_cap4(const EzrtScene* s) { // (prune 2 only: the other modes have no o
   return (c > 0 && c < s->stack_need4) ? c : s->stack_need4;
 }
 int stack_rows4(const EzrtScene* s) { return prune_mode(s) == 2 ? stack_cap4(s) + 3 : s->stack_need4; }
-// stack rows of pathq4_kernel (knob path_stage): the nearest-first traversal's cap + 3 rows of slack whenever the launch prunes
-// (it instantiates PRUNE == 2 for every prune mode != 0), and the binary depth for the in-lane re-trace in reference order
-int path_rows(const EzrtScene* s) {
-  const int wide_rows = prune_mode(s) != 0 ? stack_cap4(s) + 3 : s->stack_need4;
-  return std::max(wide_rows, s->depth + 1);
-}
 int records_staged4(const EzrtScene* s, int wps) {
   const size_t lds_fixed = (size_t)stack_rows4(s) * BLOCK * sizeof(int) + BLOCK * sizeof(int);
   size_t budget = (size_t)(158 * 1024) / (size_t)(wps > 0 ? wps : 1);
@@ -853,80 +803,59 @@ bool use_wide4(const EzrtScene* s) {
   return s->tune.wide4 && s->n_inner4 > 0 && s->instr == 0 &&
          ((size_t)s->stack_need4 + 4) * BLOCK * sizeof(int) <= 60 * 1024; // stack rows (+ 3 of slack: prune 2) + lane table
 }
-template <bool REL, bool LOG, bool GEN>
-void launch_traceq4_v(EzrtScene* s, const TraceCfg& c, const TraceQ4Args& q, hipStream_t st) {
-  const int trace_wps = wps4(s, REL);
-  const dim3 grid(c.grid_full), block(BLOCK);
+// The instances of traceq4_kernel the library ships (round 6: 19, down from 72 -- the register budgets nobody ran, the cross-wave
+// stealing variants and the scattered draw of two-ray queues are gone):
+//   primary stage, rays generated in the launch (REL + GEN): 7 waves per SIMD with the default schedule (prune 2), 6 otherwise
+//   a common origin without generation (gen_primary = 0, audit_via_queue = 2), bounce stages plain / SEMI: 6 waves, prune 0 / 1 / 2
+//   bounce stages drawn in the scattered order (GS): the default schedule only
+//   LOG (debug_stages = 2): the default schedule's five kernels
+template <bool REL, bool GEN, bool SEMI, bool GS>
+void launch_traceq4_p(int prune, bool log, int wps, dim3 grid, size_t lds, hipStream_t st, const TraceQ4Args& q) {
+  const dim3 block(BLOCK);
+  constexpr bool HAS_LOG = GEN || !REL; // (the default schedule's kernels)
+  if (prune == 2 || GS) {
+    if constexpr (REL && GEN) {
+      if (wps >= 7) {
+        if (log) hipLaunchKernelGGL((traceq4_kernel<7, REL, true, 2, GEN, SEMI, GS>), grid, block, lds, st, q);
+        else hipLaunchKernelGGL((traceq4_kernel<7, REL, false, 2, GEN, SEMI, GS>), grid, block, lds, st, q);
+        return;
+      }
+    }
+    if constexpr (HAS_LOG) {
+      if (log) {
+        hipLaunchKernelGGL((traceq4_kernel<6, REL, true, 2, GEN, SEMI, GS>), grid, block, lds, st, q);
+        return;
+      }
+    }
+    hipLaunchKernelGGL((traceq4_kernel<6, REL, false, 2, GEN, SEMI, GS>), grid, block, lds, st, q);
+    return;
+  }
+  if constexpr (!GS) {
+    if (prune == 1) hipLaunchKernelGGL((traceq4_kernel<6, REL, false, 1, GEN, SEMI, false>), grid, block, lds, st, q);
+    else hipLaunchKernelGGL((traceq4_kernel<6, REL, false, 0, GEN, SEMI, false>), grid, block, lds, st, q);
+  }
+}
+template <bool REL, bool GEN>
+void launch_traceq4_rel(EzrtScene* s, const TraceCfg& c, const TraceQ4Args& q, hipStream_t st) {
+  const int wps = wps4(s, REL);
+  const dim3 grid(c.grid_full);
   int prune = prune_mode(s);
   // (knob prune_mis: another order for the launches whose queue holds env shadow rays -- measured, not better)
   if (prune == 2 && q.q.rays_per_path == 2u && s->tune.prune_mis != 2) prune = s->tune.prune_mis;
   s->n_trace_launches++;
+  const bool log = q.q.wave_log != nullptr; // (debug_stages=2)
   // rays with an exactly-zero direction component stay in this kernel (SEMI) where they come in numbers: the env shadow
   // rays of the MIS integrators' bounce stages (two rays per path); knob semi: 0 never, 2 every launch without a common origin
   const bool semi = !REL && !GEN && (s->tune.semi == 2 || (s->tune.semi == 1 && q.q.rays_per_path == 2u));
-  // cross-wave stealing (knob xsteal; q.xs_ctl): variants of the default schedule's kernels -- pruning with the nearest-first order
-  const bool xs = q.xs_ctl != nullptr && prune == 2;
-  if (prune || GEN || semi) { // (these variants exist for the two register budgets the launches use: 7 and 6 waves per SIMD)
-    // (the scattered draw exists for the default schedule of the bounce stages: pruning with the nearest-first order, no log)
-    if (!REL && !GEN && !LOG && prune == 2 && q.gscat_shift != 0u && trace_wps < 7) {
-      if (xs) {
-        if (semi) hipLaunchKernelGGL((traceq4_kernel<6, false, false, 2, false, true, true, true>), grid, block, c.lds_t, st, q);
-        else hipLaunchKernelGGL((traceq4_kernel<6, false, false, 2, false, false, true, true>), grid, block, c.lds_t, st, q);
-      } else {
-        if (semi) hipLaunchKernelGGL((traceq4_kernel<6, false, false, 2, false, true, true>), grid, block, c.lds_t, st, q);
-        else hipLaunchKernelGGL((traceq4_kernel<6, false, false, 2, false, false, true>), grid, block, c.lds_t, st, q);
-      }
-      return;
-    }
-    if (semi) {
-      if (xs) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 2, false, !REL, false, true>), grid, block, c.lds_t, st, q);
-      else if (prune == 2) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 2, false, !REL>), grid, block, c.lds_t, st, q);
-      else if (prune == 1) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 1, false, !REL>), grid, block, c.lds_t, st, q);
-      else hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 0, false, !REL>), grid, block, c.lds_t, st, q);
-    } else if (trace_wps >= 7) {
-      if (xs) hipLaunchKernelGGL((traceq4_kernel<7, REL, LOG, 2, GEN, false, false, true>), grid, block, c.lds_t, st, q);
-      else if (prune == 2) hipLaunchKernelGGL((traceq4_kernel<7, REL, LOG, 2, GEN>), grid, block, c.lds_t, st, q);
-      else if (prune == 1) hipLaunchKernelGGL((traceq4_kernel<7, REL, LOG, 1, GEN>), grid, block, c.lds_t, st, q);
-      else hipLaunchKernelGGL((traceq4_kernel<7, REL, LOG, 0, GEN>), grid, block, c.lds_t, st, q);
-    } else {
-      if (xs) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 2, GEN, false, false, true>), grid, block, c.lds_t, st, q);
-      else if (prune == 2) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 2, GEN>), grid, block, c.lds_t, st, q);
-      else if (prune == 1) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 1, GEN>), grid, block, c.lds_t, st, q);
-      else hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG, 0, GEN>), grid, block, c.lds_t, st, q);
-    }
-    return;
-  }
-  if (trace_wps == 8) hipLaunchKernelGGL((traceq4_kernel<8, REL, LOG>), grid, block, c.lds_t, st, q);
-  else if (trace_wps == 7) hipLaunchKernelGGL((traceq4_kernel<7, REL, LOG>), grid, block, c.lds_t, st, q);
-  else if (trace_wps == 6) hipLaunchKernelGGL((traceq4_kernel<6, REL, LOG>), grid, block, c.lds_t, st, q);
-  else if (trace_wps == 4) hipLaunchKernelGGL((traceq4_kernel<4, REL, LOG>), grid, block, c.lds_t, st, q);
-  else hipLaunchKernelGGL((traceq4_kernel<5, REL, LOG>), grid, block, c.lds_t, st, q);
+  // the scattered draw exists for the default schedule of the bounce stages: pruning with the nearest-first order, one ray per path
+  const bool gs = !REL && !GEN && !semi && prune == 2 && q.gscat_shift != 0u;
+  if (REL) launch_traceq4_p<REL, GEN, false, false>(prune, log, wps, grid, c.lds_t, st, q);
+  else if (gs) launch_traceq4_p<false, false, false, true>(prune, log, wps, grid, c.lds_t, st, q);
+  else if (semi) launch_traceq4_p<false, false, true, false>(prune, log, wps, grid, c.lds_t, st, q);
+  else launch_traceq4_p<false, false, false, false>(prune, log, wps, grid, c.lds_t, st, q);
 }
-template <bool REL, bool GEN>
-void launch_traceq4_rel(EzrtScene* s, const TraceCfg& c, const TraceQ4Args& q, hipStream_t st) {
-  if (q.q.wave_log) launch_traceq4_v<REL, true, GEN>(s, c, q, st); // (debug_stages=2)
-  else launch_traceq4_v<REL, false, GEN>(s, c, q, st);
-}
-// qheads: 81 launch slots of reservation counters, then XS_CTL_WORDS control words of cross-wave stealing per group (shared by the
-// stages of a chunk: a launch leaves every group with tail == head and nobody counted)
 constexpr size_t QHEAD_SLOT_WORDS = (size_t)TRACE_HEADS * TRACE_HEAD_STRIDE;
-constexpr size_t QHEADS_WORDS = 81 * QHEAD_SLOT_WORDS + (size_t)XS_GROUPS_MAX * XS_CTL_WORDS;
-inline uint32_t* xs_ctl_of(const Pipe& pp) { return pp.qheads.p + 81 * QHEAD_SLOT_WORDS; }
-// the rings of published subtrees: all zero between launches (a taker zeroes what it takes), so zeroed once, when allocated
-hipError_t ensure_xs_ring(Pipe& pp, hipStream_t st) {
-  const size_t n = (size_t)XS_GROUPS_MAX * XS_GRING;
-  if (pp.xs_ring.n >= n) return hipSuccess;
-  hipError_t e = pp.xs_ring.ensure(n);
-  if (e != hipSuccess) return e;
-  e = hipMemsetAsync(pp.xs_ring.p, 0, n * sizeof(unsigned long long), st);
-  if (e != hipSuccess) return e;
-  return hipStreamSynchronize(st); // (the chunk may run on another stream than `st`; once per scratch set)
-}
-inline uint32_t xs_groups(const EzrtScene* s) { // the knob, rounded down to a power of two
-  uint32_t g = 16u;
-  while (g * 2u <= (uint32_t)s->tune.xsteal_groups && g * 2u <= XS_GROUPS_MAX) g *= 2u;
-  return g;
-}
+constexpr size_t QHEADS_WORDS = 81 * QHEAD_SLOT_WORDS; // launch slots of reservation counters: stage b, redo launch 40 + b
 
 // t: the stage's queue arguments as for the binary kernel (knobs already filled); rel: 4-wide records translated by
 // t.origin (or NULL)
@@ -967,25 +896,14 @@ void fill_traceq4_args(const EzrtScene* s, const TraceCfg& c4, const TraceQArgs&
   // (the even / odd slots of a two-ray path must stay in one granule: any granule >= 2 slots does)
   // knob bounce_scatter: 1 (default) = queues with one ray per path only.  Measured in the pipeline (profiles/r4/bounce_scatter_ab.txt):
   // C2 +2.7 % (trace launches 1.39 -> 1.345 ms), C3 -0.5 % (noise); the MIS integrators' queues (two rays per path sharing an
-  // origin, env shadow rays that are coherent by construction) LOSE 1.3 % (C4) and 2.8 % (C5) with it: 2 = those too
-  A.gscat_shift = (!rel && !gen && !t.slot_map && (s->tune.bounce_scatter == 2 || (s->tune.bounce_scatter == 1 && t.rays_per_path == 1u))) ? 3u : 0u;
-  A.xs_ctl = nullptr; // (cross-wave stealing: set by launch_traceq4_cfg for the launches that have a ring)
-  A.xs_ring = nullptr;
-  A.xs_stock = (uint32_t)s->tune.xsteal_stock;
-  A.xs_gmask = xs_groups(s) - 1u;
-  A.xs_min_idle = (uint32_t)s->tune.xsteal_min_idle;
+  // origin, env shadow rays that are coherent by construction) LOST 1.3 % (C4) and 2.8 % (C5) with it: never scattered
+  A.gscat_shift = (!rel && !gen && !t.slot_map && s->tune.bounce_scatter != 0 && t.rays_per_path == 1u) ? 3u : 0u;
   A.handover = (s->tune.handover && t.steal) ? 1u : 0u;
   A.steal_bound = s->tune.steal_bound ? 1u : 0u;
 }
-// xs_ctl / xs_ring (or NULL): this launch's control words and the scratch set's ring of published subtrees (knob xsteal)
-void launch_traceq4_cfg(EzrtScene* s, const TraceCfg& c4, const TraceQArgs& t, const float4* rel, hipStream_t st, const WfArgs* gen = nullptr,
-                        uint32_t* xs_ctl = nullptr, unsigned long long* xs_ring = nullptr) {
+void launch_traceq4_cfg(EzrtScene* s, const TraceCfg& c4, const TraceQArgs& t, const float4* rel, hipStream_t st, const WfArgs* gen = nullptr) {
   TraceQ4Args A;
   fill_traceq4_args(s, c4, t, rel, gen, A);
-  if (s->tune.xsteal && t.steal && !t.slot_map && xs_ctl && xs_ring) {
-    A.xs_ctl = xs_ctl;
-    A.xs_ring = xs_ring;
-  }
   if (rel && gen) launch_traceq4_rel<true, true>(s, c4, A, st);
   else if (rel) launch_traceq4_rel<true, false>(s, c4, A, st);
   else launch_traceq4_rel<false, false>(s, c4, A, st);
@@ -1011,54 +929,54 @@ void fill_trace_knobs(const EzrtScene* s, const TraceCfg& c, TraceQArgs& t) {
 }
 
 // ---- wavefront pipeline for one chunk of frames (all launches asynchronous on `st`)
-template <int INTEG, int STAGE>
-void launch_shade_is(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
-  if (full) hipLaunchKernelGGL((shade_kernel<INTEG, true, STAGE>), grid, dim3(SHADE_BLOCK), 0, st, a);
-  else hipLaunchKernelGGL((shade_kernel<INTEG, false, STAGE>), grid, dim3(SHADE_BLOCK), 0, st, a);
-}
+// Shading kernels the library ships (round 6: 40 instances, down from 90).  The timed route: the primary stage and bounce 1 --
+// the two big stages -- run shade_miss_kernel + shade_hit_kernel (leaving paths in 45 VGPRs, surface interactions in dense waves),
+// the small later stages the fused shade_kernel (one launch less each).  The instrumented route (FULLCTR: the env-lookup
+// counters of SURVEY 8(d)) runs the fused kernel in every stage.  (The fused kernel for the big stages, +12 % time, and the
+// split pair for the small ones, -0.6 %, were knob `split_shade` until round 6.)
 template <int INTEG>
-void launch_shade_i(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
-  if (a.bounce == 0) launch_shade_is<INTEG, 0>(a, full, grid, st);
-  else if (a.bounce == 1) launch_shade_is<INTEG, 1>(a, full, grid, st);
-  else launch_shade_is<INTEG, 2>(a, full, grid, st);
+void launch_shade_fused_i(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
+  if (full) {
+    if (a.bounce == 0) hipLaunchKernelGGL((shade_kernel<INTEG, true, 0>), grid, dim3(SHADE_BLOCK), 0, st, a);
+    else if (a.bounce == 1) hipLaunchKernelGGL((shade_kernel<INTEG, true, 1>), grid, dim3(SHADE_BLOCK), 0, st, a);
+    else hipLaunchKernelGGL((shade_kernel<INTEG, true, 2>), grid, dim3(SHADE_BLOCK), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((shade_kernel<INTEG, false, 2>), grid, dim3(SHADE_BLOCK), 0, st, a); // (bounce >= 2: see launch_shade)
+  }
 }
 // `between` (or NULL): an event the second pass waits for -- the stage's redo launch on the side stream
 // Returns the status of the cross-stream wait: if it failed, the second pass was NOT launched (it would read hit records
 // the redo launch is still writing) and the caller fails the render call.
 template <int INTEG, int STAGE>
-hipError_t launch_shade_split_ib(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st, hipEvent_t between) {
-  if (full) hipLaunchKernelGGL((shade_miss_kernel<INTEG, true, STAGE>), grid, dim3(SHADE_BLOCK), 0, st, a);
-  else hipLaunchKernelGGL((shade_miss_kernel<INTEG, false, STAGE>), grid, dim3(SHADE_BLOCK), 0, st, a);
+hipError_t launch_shade_split_ib(const WfArgs& a, dim3 grid, dim3 grid_hit, hipStream_t st, hipEvent_t between) {
+  hipLaunchKernelGGL((shade_miss_kernel<INTEG, false, STAGE>), grid, dim3(SHADE_BLOCK), 0, st, a);
   if (between) {
     const hipError_t e = hipStreamWaitEvent(st, between, 0);
     if (e != hipSuccess) return e;
   }
-  if (full) hipLaunchKernelGGL((shade_hit_kernel<INTEG, true, STAGE>), grid_hit, dim3(SHADE_BLOCK), 0, st, a);
-  else hipLaunchKernelGGL((shade_hit_kernel<INTEG, false, STAGE>), grid_hit, dim3(SHADE_BLOCK), 0, st, a);
+  hipLaunchKernelGGL((shade_hit_kernel<INTEG, false, STAGE>), grid_hit, dim3(SHADE_BLOCK), 0, st, a);
   return hipSuccess;
 }
 template <int INTEG>
-hipError_t launch_shade_split_i(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st, hipEvent_t between) {
-  if (a.bounce == 0) return launch_shade_split_ib<INTEG, 0>(a, full, grid, grid_hit, st, between);
-  if (a.bounce == 1) return launch_shade_split_ib<INTEG, 1>(a, full, grid, grid_hit, st, between);
-  return launch_shade_split_ib<INTEG, 2>(a, full, grid, grid_hit, st, between);
-}
-hipError_t launch_shade_split(const WfArgs& a, bool full, dim3 grid, dim3 grid_hit, hipStream_t st, hipEvent_t between) {
-  switch (a.p.integrator) {
-    case EZRT_INTEGRATOR_P3_DIFFUSE: return launch_shade_split_i<EZRT_INTEGRATOR_P3_DIFFUSE>(a, full, grid, grid_hit, st, between);
-    case EZRT_INTEGRATOR_P4_DISNEY: return launch_shade_split_i<EZRT_INTEGRATOR_P4_DISNEY>(a, full, grid, grid_hit, st, between);
-    case EZRT_INTEGRATOR_P5_SOBOL: return launch_shade_split_i<EZRT_INTEGRATOR_P5_SOBOL>(a, full, grid, grid_hit, st, between);
-    case EZRT_INTEGRATOR_P5_MIS_ANISO: return launch_shade_split_i<EZRT_INTEGRATOR_P5_MIS_ANISO>(a, full, grid, grid_hit, st, between);
-    default: return launch_shade_split_i<EZRT_INTEGRATOR_P5_MIS>(a, full, grid, grid_hit, st, between);
+hipError_t launch_shade_i(const WfArgs& a, bool full, dim3 grid, hipStream_t st, hipEvent_t between) {
+  if (!full && a.bounce == 0) return launch_shade_split_ib<INTEG, 0>(a, grid, grid, st, between);
+  if (!full && a.bounce == 1) return launch_shade_split_ib<INTEG, 1>(a, grid, grid, st, between);
+  if (between) { // (the fused kernel reads every hit record at once: behind the redo launch)
+    const hipError_t e = hipStreamWaitEvent(st, between, 0);
+    if (e != hipSuccess) return e;
   }
+  launch_shade_fused_i<INTEG>(a, full, grid, st);
+  return hipSuccess;
 }
-void launch_shade(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
+// whether stage b's shading is the split pair (the caller's redo launch may then overlap the first pass)
+inline bool shade_is_split(bool full, int bounce) { return !full && bounce <= 1; }
+hipError_t launch_shade(const WfArgs& a, bool full, dim3 grid, hipStream_t st, hipEvent_t between) {
   switch (a.p.integrator) {
-    case EZRT_INTEGRATOR_P3_DIFFUSE: launch_shade_i<EZRT_INTEGRATOR_P3_DIFFUSE>(a, full, grid, st); break;
-    case EZRT_INTEGRATOR_P4_DISNEY: launch_shade_i<EZRT_INTEGRATOR_P4_DISNEY>(a, full, grid, st); break;
-    case EZRT_INTEGRATOR_P5_SOBOL: launch_shade_i<EZRT_INTEGRATOR_P5_SOBOL>(a, full, grid, st); break;
-    case EZRT_INTEGRATOR_P5_MIS_ANISO: launch_shade_i<EZRT_INTEGRATOR_P5_MIS_ANISO>(a, full, grid, st); break;
-    default: launch_shade_i<EZRT_INTEGRATOR_P5_MIS>(a, full, grid, st); break;
+    case EZRT_INTEGRATOR_P3_DIFFUSE: return launch_shade_i<EZRT_INTEGRATOR_P3_DIFFUSE>(a, full, grid, st, between);
+    case EZRT_INTEGRATOR_P4_DISNEY: return launch_shade_i<EZRT_INTEGRATOR_P4_DISNEY>(a, full, grid, st, between);
+    case EZRT_INTEGRATOR_P5_SOBOL: return launch_shade_i<EZRT_INTEGRATOR_P5_SOBOL>(a, full, grid, st, between);
+    case EZRT_INTEGRATOR_P5_MIS_ANISO: return launch_shade_i<EZRT_INTEGRATOR_P5_MIS_ANISO>(a, full, grid, st, between);
+    default: return launch_shade_i<EZRT_INTEGRATOR_P5_MIS>(a, full, grid, st, between);
   }
 }
 
@@ -1118,12 +1036,11 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
   const size_t n_slots = (size_t)nb * BLOCK * nf;
   if (p->max_bounce > 32) return fail(EZRT_ERR_UNSUPPORTED, "max_bounce > 32: more stages than this build has queue counters for");
   HIP_TRY(ensure_chunk_scratch(s, pp, n_slots, mis, st)); // (a no-op after ezrt_render_device's sizing pass)
-  // [0..63] paths per stage, [64..99] queue heads, [100..119] debug, [120,121] packet redo,
+  // [0..63] paths per stage, [64..99] queue heads, [100..119] debug,
   // [128..] redo counts per stage, [192..] redo queue heads per stage
-  constexpr size_t HEAD_SLOT = (size_t)TRACE_HEADS * TRACE_HEAD_STRIDE; // launch slots: stage b, redo 40 + b, packet redo 80
+  constexpr size_t HEAD_SLOT = (size_t)TRACE_HEADS * TRACE_HEAD_STRIDE; // launch slots: stage b, redo 40 + b
   HIP_TRY(pp.qheads.ensure(QHEADS_WORDS)); // (both zeroed by raygen_kernel: ChunkPrologue)
   HIP_TRY(pp.qcounts.ensure(320));
-  if (s->tune.xsteal) HIP_TRY(ensure_xs_ring(pp, st));
   {
     int rc_cu = ensure_num_cus(s);
     if (rc_cu) return rc_cu;
@@ -1211,7 +1128,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     pro.n_inner4 = s->n_inner4;
   }
   // primary rays generated where they are consumed (primary_dir) when stage 0 runs the 4-wide kernel on eye-relative records
-  const bool gen_primary = wide && s->tune.rel_boxes && s->tune.gen_primary && !s->tune.packet;
+  const bool gen_primary = wide && s->tune.rel_boxes && s->tune.gen_primary;
   a.all_owned = (p->shard_count <= 1 && p->x0 == 0 && p->y0 == 0 && p->x1 == p->width && p->y1 == p->height && p->width % 16 == 0 &&
                  p->height % 16 == 0 && s->tune.lazy_dir) ? 1u : 0u;
   a.gen_primary = 0u; // (the shading passes read the directions the trace launch stored: see traceq4_kernel GEN)
@@ -1224,7 +1141,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
 
   const Tuning& tu = s->tune;
   const TraceCfg cfg = trace_cfg(s);
-  const int use_packet = tu.packet, packet_budget = tu.packet_budget, debug_stages = tu.debug_stages;
+  const int debug_stages = tu.debug_stages;
   const unsigned trace_grid_full = cfg.grid_full;
   unsigned shade_grid = (unsigned)((n_slots + SHADE_BLOCK - 1) / SHADE_BLOCK);
   unsigned shade_grid_max = s->tune.shade_wgs > 0 ? (unsigned)s->tune.shade_wgs : (unsigned)(12 * s->num_cus);
@@ -1232,93 +1149,8 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
   if (shade_grid_max < 1u) shade_grid_max = 1u;
   if (shade_grid > shade_grid_max) shade_grid = shade_grid_max;
 
-  const int tail_from = (!full && !plog && !debug_stages && tu.tail_stage >= 2) ? tu.tail_stage : (1 << 30);
-  // (a tree so deep that the fused launch's stack rows + lane table exceed the 64 KiB a launch gets without opt-in keeps the staged stages)
-  const bool path_fits = ((size_t)path_rows(s) + 1) * BLOCK * sizeof(int) <= 64 * 1024;
-  const int path_from = (!full && !plog && !debug_stages && !mis && wide && tu.path_stage >= 2 && path_fits) ? tu.path_stage : (1 << 30);
   for (int b = 0; b <= p->max_bounce; b++) {
     const int in = b & 1, out = in ^ 1;
-    if (b >= path_from && b < tail_from) { // every later bounce of the chunk in one persistent launch (pathq4_kernel)
-      a.rq_in = queue(in);
-      a.st_in = state(in);
-      a.n_in = pp.qcounts.p + b;
-      a.bounce = b;
-      // LDS: stack rows for the nearest-first traversal AND for the in-lane reference-order re-trace (binary depth), the
-      // lane table, then top-of-tree records; 4 workgroups per CU (the kernel is compiled for <= 128 VGPRs)
-      TraceCfg c;
-      // (the launch below always instantiates the nearest-first template when it prunes at all, whatever the knob says, and
-      // that order pushes up to three rows before its cap is tested: size for cap + 3 -- ADVICE r3)
-      const int rows = path_rows(s);
-      c.lds = (size_t)rows * BLOCK * sizeof(int);
-      const size_t lds_fixed = c.lds + BLOCK * sizeof(int);
-      size_t budget = (size_t)(158 * 1024) / 4;
-      budget -= budget / 16;
-      int nrec = budget > lds_fixed ? (int)((budget - lds_fixed) / (N4_LDS_DWORDS * 4)) : 0;
-      nrec = std::min(nrec, std::min(s->n_inner4, tu.lds_nodes));
-      c.lds_nodes = nrec < 0 ? 0 : nrec;
-      c.lds_t = lds_fixed + (size_t)c.lds_nodes * (N4_LDS_DWORDS * 4); // (<= 64 KiB: path_fits)
-      c.blocks_per_cu = lds_fixed > budget ? std::max(1, (int)((size_t)(158 * 1024) / lds_fixed)) : 4;
-      c.grid_full = (unsigned)(s->num_cus * c.blocks_per_cu);
-      TraceQArgs t;
-      t.sc = trace_scene(a.sc);
-      t.rq = queue(in);
-      t.hits = pp.hits2[in].p;
-      t.n_paths = pp.qcounts.p + b;
-      t.rays_per_path = 1u;
-      t.const_origin = 0u;
-      t.inner_rel = nullptr;
-      t.origin[0] = t.origin[1] = t.origin[2] = 0.0f;
-      t.head = pp.qheads.p + (size_t)b * HEAD_SLOT;
-      t.counters = s->counters.p;
-      fill_trace_knobs(s, c, t);
-      if (tu.path_refill_min > 0) t.refill_min = (uint32_t)tu.path_refill_min; // (a finished lane waits for the batch before it is shaded)
-      t.dbg = nullptr;
-      t.slot_map = nullptr;
-      t.steal = 0u;
-      t.count_rays = 1u;
-      t.redo_count = pp.qcounts.p + 128 + b;
-      t.redo_slots = pp.redo_slots.p;
-      t.redo_flag = pp.redo_flag.p;
-      t.force_pending = (uint32_t)tu.debug_force_pending;
-      t.wave_log = nullptr;
-      TraceQ4Args A;
-      fill_traceq4_args(s, c, t, nullptr, nullptr, A);
-      const bool pr = prune_mode(s) != 0;
-      const dim3 grid(c.grid_full), block(BLOCK);
-      switch (p->integrator) {
-        case EZRT_INTEGRATOR_P3_DIFFUSE:
-          if (pr) hipLaunchKernelGGL((pathq4_kernel<EZRT_INTEGRATOR_P3_DIFFUSE, 2>), grid, block, c.lds_t, st, A, a);
-          else hipLaunchKernelGGL((pathq4_kernel<EZRT_INTEGRATOR_P3_DIFFUSE, 0>), grid, block, c.lds_t, st, A, a);
-          break;
-        case EZRT_INTEGRATOR_P4_DISNEY:
-          if (pr) hipLaunchKernelGGL((pathq4_kernel<EZRT_INTEGRATOR_P4_DISNEY, 2>), grid, block, c.lds_t, st, A, a);
-          else hipLaunchKernelGGL((pathq4_kernel<EZRT_INTEGRATOR_P4_DISNEY, 0>), grid, block, c.lds_t, st, A, a);
-          break;
-        default:
-          if (pr) hipLaunchKernelGGL((pathq4_kernel<EZRT_INTEGRATOR_P5_SOBOL, 2>), grid, block, c.lds_t, st, A, a);
-          else hipLaunchKernelGGL((pathq4_kernel<EZRT_INTEGRATOR_P5_SOBOL, 0>), grid, block, c.lds_t, st, A, a);
-          break;
-      }
-      s->n_trace_launches++;
-      break;
-    }
-    if (b >= tail_from) { // the few paths still alive finish here, one lane each
-      a.rq_in = queue(in);
-      a.st_in = state(in);
-      a.n_in = pp.qcounts.p + b;
-      a.bounce = b;
-      unsigned tg = (unsigned)(s->num_cus * 8);
-      if ((size_t)tg * BLOCK > n_slots) tg = (unsigned)((n_slots + BLOCK - 1) / BLOCK);
-      const size_t tl = stack_lds_bytes(s);
-      switch (p->integrator) {
-        case EZRT_INTEGRATOR_P3_DIFFUSE: hipLaunchKernelGGL((tail_kernel<EZRT_INTEGRATOR_P3_DIFFUSE>), dim3(tg), dim3(BLOCK), tl, st, a, s->depth); break;
-        case EZRT_INTEGRATOR_P4_DISNEY: hipLaunchKernelGGL((tail_kernel<EZRT_INTEGRATOR_P4_DISNEY>), dim3(tg), dim3(BLOCK), tl, st, a, s->depth); break;
-        case EZRT_INTEGRATOR_P5_SOBOL: hipLaunchKernelGGL((tail_kernel<EZRT_INTEGRATOR_P5_SOBOL>), dim3(tg), dim3(BLOCK), tl, st, a, s->depth); break;
-        case EZRT_INTEGRATOR_P5_MIS_ANISO: hipLaunchKernelGGL((tail_kernel<EZRT_INTEGRATOR_P5_MIS_ANISO>), dim3(tg), dim3(BLOCK), tl, st, a, s->depth); break;
-        default: hipLaunchKernelGGL((tail_kernel<EZRT_INTEGRATOR_P5_MIS>), dim3(tg), dim3(BLOCK), tl, st, a, s->depth); break;
-      }
-      break;
-    }
     TraceQArgs t;
     t.sc = trace_scene(a.sc);
     t.rq = queue(in);
@@ -1349,10 +1181,10 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
       t.wave_log = pp.wave_log.p;
     }
     auto launch_traceq = [&](const TraceQArgs& q, bool small = false) { launch_traceq_cfg(s, cfg, q, small, st); };
-    const bool split_here = tu.split_shade == 3 ? b <= 1 : ((b >= 1 && tu.split_shade) || tu.split_shade >= 2);
+    const bool split_here = shade_is_split(full, b);
     // the redo launch under the first shading pass: only where the first pass cannot be misled by a record the redo
     // launch is still to write -- traceq4_kernel marks those HIT_PENDING -- and only in plain timed runs
-    const bool overlap_redo = wide && split_here && tu.redo_overlap && !full && !plog && !debug_stages && !(b == 0 && use_packet);
+    const bool overlap_redo = wide && split_here && tu.redo_overlap && !full && !plog && !debug_stages;
     hipEvent_t ev_between = nullptr;
     int e = tu.launch_events ? s->n_trace_events : MAX_TRACE_EVENTS;
     if (e < MAX_TRACE_EVENTS) {
@@ -1364,42 +1196,10 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
       }
       HIP_TRY(hipEventRecord(s->ev_trace[e][0], st));
     }
-    if (b == 0 && !full && use_packet) {
-      // primary rays: packet traversal (one wave = one 8x8 tile); rays with an exact distance tie and
-      // rays of over-budget packets go to a redo list that the per-lane kernel traces in reference order
-      TracePkArgs k;
-      k.tri_geom = s->tri_geom.p;
-      k.inner = s->inner.p;
-      k.root_ref = s->root_ref;
-      k.rq = queue(in);
-      k.hits = pp.hits2[in].p;
-      k.n_rays = (uint32_t)n_slots;
-      k.counters = s->counters.p;
-      k.redo_count = pp.qcounts.p + 120;
-      k.redo_slots = pp.redo_slots.p;
-      k.stack_entries = s->depth + 1;
-      k.budget = packet_budget;
-      k.origin[0] = p->eye[0];
-      k.origin[1] = p->eye[1];
-      k.origin[2] = p->eye[2];
-      k.dbg = debug_stages ? (pp.qcounts.p + 116) : nullptr;
-      const size_t lds_pk = (size_t)(BLOCK / 64) * k.stack_entries * 3 * sizeof(int);
-      unsigned pk_grid = (unsigned)(s->num_cus * 7); // 66 VGPRs: 7 waves/SIMD = 7 workgroups of 4 waves per CU
-      if ((size_t)pk_grid * BLOCK > n_slots) pk_grid = (unsigned)((n_slots + BLOCK - 1) / BLOCK);
-      hipLaunchKernelGGL(tracepk_kernel, dim3(pk_grid), dim3(BLOCK), lds_pk, st, k);
-      s->n_trace_launches++;
-      t.slot_map = pp.redo_slots.p;
-      t.n_paths = pp.qcounts.p + 120;
-      t.head = pp.qheads.p + (size_t)80 * HEAD_SLOT;
-      t.rays_per_path = 1u;
-      t.steal = 0u;
-      t.redo_flag = nullptr;
-      launch_traceq(t);
-    } else {
+    {
       if (wide) {
         const bool rel = b == 0 && tu.rel_boxes;
-        launch_traceq4_cfg(s, rel ? cfg4_rel : cfg4_abs, t, rel ? pp.inner4_rel.p : nullptr, st, (rel && gen_primary) ? &a : nullptr,
-                           xs_ctl_of(pp), pp.xs_ring.p);
+        launch_traceq4_cfg(s, rel ? cfg4_rel : cfg4_abs, t, rel ? pp.inner4_rel.p : nullptr, st, (rel && gen_primary) ? &a : nullptr);
       }
       else launch_traceq(t);
       if (t.steal || wide) { // rays that met an exact distance tie, or (4-wide) are not tame -- normally none: reference order, plain stores
@@ -1470,8 +1270,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     a.bounce = b;
     a.defer_list = pp.defer_list.p;
     a.defer_count = pp.defer_count.p;
-    if (split_here) HIP_TRY(launch_shade_split(a, full, dim3(shade_grid), dim3(shade_grid), st, ev_between));
-    else launch_shade(a, full, dim3(shade_grid), st);
+    HIP_TRY(launch_shade(a, full, dim3(shade_grid), st, ev_between));
     if (debug_stages) { // diagnostic only: per-stage queue sizes and counters (synchronises)
       uint32_t q[2] = {0, 0};
       unsigned long long c[EZRT_CTR_COUNT];
@@ -1485,11 +1284,6 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
           for (int j = 0; j < CTR_SLOTS; j++) c[k] += all[j * EZRT_CTR_COUNT + k];
         }
       }
-      if (b == 0 && use_packet && !full) {
-        uint32_t pk[3] = {0, 0, 0};
-        HIP_TRY(hipMemcpy(pk, pp.qcounts.p + 116, sizeof pk, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[ezrt] packet stage: wave inner steps %u, wave triangle steps %u, max steps of one wave %u\n", pk[0], pk[1], pk[2]);
-      }
       if (debug_stages >= 2 && t.wave_log) { // per-wave life times of this stage's traceq launch
         const size_t nw = (size_t)trace_grid_full * (BLOCK / 64);
         std::vector<unsigned long long> w(nw * 8);
@@ -1497,7 +1291,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
         unsigned long long t0 = ~0ull;
         for (size_t i = 0; i < nw; i++)
           if (w[i * 8] && w[i * 8] < t0) t0 = w[i * 8];
-        unsigned long long s_it = 0, s_is = 0, s_il = 0, s_ll = 0, s_lr = 0, s_busy = 0, s_rf = 0, s_st = 0, s_xg = 0, s_xt = 0;
+        unsigned long long s_it = 0, s_is = 0, s_il = 0, s_ll = 0, s_lr = 0, s_busy = 0, s_rf = 0, s_st = 0;
         std::vector<double> endt, life, its, rays, startt, exht, after;
         for (size_t i = 0; i < nw; i++)
           if (w[i * 8]) {
@@ -1516,8 +1310,6 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
             s_ll += (uint32_t)w[i * 8 + 4];
             s_lr += w[i * 8 + 4] >> 32;
             s_busy += (uint32_t)w[i * 8 + 5];
-            s_xg += (w[i * 8 + 5] >> 32) & 0xffffu;
-            s_xt += w[i * 8 + 5] >> 48;
             s_rf += (uint32_t)w[i * 8 + 6];
             s_st += w[i * 8 + 6] >> 32;
           }
@@ -1536,8 +1328,8 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
         if (!exht.empty())
           fprintf(stderr, "[ezrt]   queue found empty at us p10 %.1f p50 %.1f p90 %.1f max %.1f | a wave then runs on for us p10 %.1f p50 %.1f p90 %.1f max %.1f\n",
                   pct(exht, 0.1), pct(exht, 0.5), pct(exht, 0.9), pct(exht, 1.0), pct(after, 0.1), pct(after, 0.5), pct(after, 0.9), pct(after, 1.0));
-        fprintf(stderr, "[ezrt]   refill block in %.0f %% of the iterations, steal block in %.0f %% | across waves: %llu subtrees published, %llu claimed\n",
-                100.0 * (double)s_rf / (double)(s_it ? s_it : 1), 100.0 * (double)s_st / (double)(s_it ? s_it : 1), s_xg, s_xt);
+        fprintf(stderr, "[ezrt]   refill block in %.0f %% of the iterations, steal block in %.0f %%\n",
+                100.0 * (double)s_rf / (double)(s_it ? s_it : 1), 100.0 * (double)s_st / (double)(s_it ? s_it : 1));
       }
       uint32_t dbg[3] = {0, 0, 0};
       HIP_TRY(hipMemcpy(dbg, pp.qcounts.p + 100 + 4 * (b & 3), sizeof dbg, hipMemcpyDeviceToHost));
@@ -1546,20 +1338,6 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
         uint32_t redo_n = 0;
         HIP_TRY(hipMemcpy(&redo_n, pp.qcounts.p + 128 + b, sizeof redo_n, hipMemcpyDeviceToHost));
         fprintf(stderr, "[ezrt] stage %d: %u rays re-traced in reference order (exact ties / not tame)\n", b, redo_n);
-        if (wide && s->tune.xsteal) { // cross-wave stealing: the groups' control words as the launches so far left them (cumulative over the chunk)
-          const uint32_t ng = xs_groups(s);
-          std::vector<uint32_t> xc((size_t)ng * XS_CTL_WORDS);
-          HIP_TRY(hipMemcpy(xc.data(), xs_ctl_of(pp), xc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-          unsigned long long pub = 0, clm = 0, busy = 0, err = 0;
-          for (uint32_t g = 0; g < ng; g++) {
-            pub += xc[(size_t)g * XS_CTL_WORDS];
-            clm += xc[(size_t)g * XS_CTL_WORDS + 1];
-            busy += xc[(size_t)g * XS_CTL_WORDS + XS_BUSY];
-            err += xc[(size_t)g * XS_CTL_WORDS + XS_ERR];
-          }
-          fprintf(stderr, "[ezrt] stage %d: across waves (%u groups, chunk so far): %llu subtrees published, %llu claimed, lost entries %llu, busy count left %llu\n",
-                  b, ng, pub, clm, err, busy);
-        }
       }
       fprintf(stderr, "[ezrt] stage %d: paths_in %u paths_out %u | cum rays %llu pops %llu inner %llu tris %llu | max/ray pops %u tris %u iters %u\n", b, q[0],
               q[1], c[0], c[1], c[2], c[3], dbg[0], dbg[1], dbg[2]);
@@ -2322,13 +2100,6 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
     if (chunk < 1) chunk = 1;
     if (chunk > p->spp) chunk = p->spp;
     const int use_mega = s->tune.megakernel;
-    // pipelined: the call's frames in sub-chunks that alternate between the two pipes (own streams)
-    int n_pipes = (!use_mega && s->tune.pipes >= 2 && p->spp >= 2 && !s->tune.debug_stages) ? 2 : 1;
-    if (n_pipes == 2) {
-      size_t half = (p->spp + 1) / 2;
-      if (s->tune.sub_frames > 0 && (size_t)s->tune.sub_frames < half) half = (size_t)s->tune.sub_frames;
-      if (chunk > half) chunk = half;
-    }
     // Chunks pipelined ACROSS calls (knob pipeline_calls, round 4): chunk i of the scene's life runs on scratch set i & 1 and that
     // set's own stream.  Nothing it does touches the caller's memory -- it reads the scene and writes its own queues and samples --
     // so it need not wait for anything the caller queued before this call; the kernel that DOES touch the caller's frame buffer,
@@ -2344,20 +2115,13 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
     // = 0) every config gains: C3 +3.0 %, C4 +2.6 %, C5 +1.8 %, C2 unchanged at +13 %.  So every scene is pipelined.
     // (not with per-launch timing events: they sit on the chunk's stream while the call's begin / end events sit on the caller's, and two
     // overlapping chunks would have their launch intervals summed twice -- ezrt_last_render_ms describes calls run one chunk at a time)
-    const bool xcall = !use_mega && n_pipes == 1 && !s->tune.debug_stages && s->tune.pipeline_calls != 0 && !s->tune.launch_events;
-    // How many chunks may be in flight (knob pipeline_depth; round 5): 2 scratch sets and streams (default), 3 or 4.
-    // Measured (profiles/r5/pipeline_depth_ab.txt): in a BURST of three calls a third set lets all three overlap -- C2 12.7-12.8 ->
-    // 13.2-13.3 Grays/s, C4 15.55 -> 16.09, C3 7.39 -> 7.68; depth 4 is back at depth 2's rate (a fourth stream shares a hardware queue:
-    // ezrt_streams.h) -- but in steady state (bench.py's windows of 20 steps) depth 3 = depth 2 to four digits (14 943 vs 14 943 Mrays/s):
-    // two chunks in flight already keep the chip as busy as three.  SMALL chunks -- the 1/2, 1/4, 1/8 shards of a C2 frame -- LOSE 3-10 %
-    // at depth 3 or 4 (0.53 -> 0.56-0.59 ms for the eighth: the opposite of VERDICT r4's expectation; every launch of such a chunk is
-    // latency-bound and three half-empty launches contend for the CUs of the same few deep rays).  A third scratch set costs up to 23 GB
-    // (C5 at 2^26 samples in flight), so the default stays 2; 0 = 2.
-    int depth = s->tune.pipeline_depth;
-    if (depth <= 0) depth = 2;
-    if (depth > ezh::SHARED_STREAMS) depth = ezh::SHARED_STREAMS;
-    if (depth < 2) depth = 2;
-    const int n_scratch = xcall ? depth : n_pipes;
+    const bool xcall = !use_mega && !s->tune.debug_stages && s->tune.pipeline_calls != 0 && !s->tune.launch_events;
+    // Two chunks in flight.  (Round 5 measured three and four -- knob pipeline_depth, removed in round 6: a BURST of three calls gained
+    // 4 % with a third scratch set, the steady state of back-to-back calls was identical to four digits, the 1/2 .. 1/8 shards of a
+    // frame LOST 3-10 %, and a third set costs up to 23 GB: profiles/r5/pipeline_depth_ab.txt.  So did splitting one call's frames into
+    // sub-chunks on two streams -- knob pipes, round 2: every stage's latency-bound end is paid twice, 3.81 vs 3.65 ms.)
+    constexpr int depth = 2;
+    const int n_scratch = xcall ? depth : 1;
     if (!use_mega) { // size the chunk's queues now: if they do not fit, halve the chunk (same results, more launches)
       const bool mis = p->integrator == EZRT_INTEGRATOR_P5_MIS || p->integrator == EZRT_INTEGRATOR_P5_MIS_ANISO;
       for (;;) {
@@ -2375,17 +2139,15 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
       }
     }
     const size_t lds = stack_lds_bytes(s);
-    uint32_t k = 0;
-    for (uint32_t done = 0; done < p->spp; k++) {
+    for (uint32_t done = 0; done < p->spp;) {
       uint32_t nf = (uint32_t)((p->spp - done < chunk) ? (p->spp - done) : chunk);
-      Pipe& q = s->pipe[xcall ? (s->chunk_seq % (uint32_t)depth) : (n_pipes == 2 ? (k & 1u) : 0u)];
-      hipStream_t qs = (xcall || n_pipes == 2) ? q.stream : st;
+      Pipe& q = s->pipe[xcall ? (s->chunk_seq % (uint32_t)depth) : 0u];
+      hipStream_t qs = xcall ? q.stream : st;
       HIP_TRY(q.samples.ensure(per_frame * chunk));
-      if (xcall) { // after the accumulation that consumed this scratch set's previous samples (two chunks ago)
-        if (q.free_recorded) HIP_TRY(hipStreamWaitEvent(qs, q.ev_free, 0));
-      } else if (n_pipes == 2) { // after everything queued before the call and after this pipe's previous sub-chunk was consumed
-        HIP_TRY(hipStreamWaitEvent(qs, k < 2 ? s->ev_begin : q.ev_free, 0));
-      }
+      // after the accumulation that consumed this scratch set's previous samples: two chunks ago when pipelined; in the plain route
+      // (launch_events, debug_stages, knob off) the previous user may have been a pipelined call whose accumulation sits on ANOTHER
+      // caller stream (toggling launch_events, as bench.py does, made that race easy to reach)
+      if (q.free_recorded) HIP_TRY(hipStreamWaitEvent(qs, q.ev_free, 0));
       if (use_mega) {
         TraceArgs a;
         a.sc = s->dev();
@@ -2413,7 +2175,7 @@ int ezrt_render_device(EzrtScene* s, const EzrtRenderParams* p, float* accum_dev
         s->chunk_pipelined = false;
         if (rc) return rc;
       }
-      if (xcall || n_pipes == 2) { // the running mean is applied in frame order, on the caller's stream
+      if (xcall) { // the running mean is applied in frame order, on the caller's stream
         HIP_TRY(hipEventRecord(q.ev_done, qs));
         HIP_TRY(hipStreamWaitEvent(st, q.ev_done, 0));
       }
@@ -2496,6 +2258,27 @@ int ezrt_frame_read(const float* frame_dev, int width, int height, float* rgba_h
 int ezrt_frame_write(float* frame_dev, int width, int height, const float* rgba_host) {
   if (!frame_dev || !rgba_host || width <= 0 || height <= 0) return fail(EZRT_ERR_INVALID, "bad frame arguments");
   return frame_copy(frame_dev, const_cast<float*>(rgba_host), (size_t)width * height * sizeof(float4), false);
+}
+
+int ezrt_frame_nonfinite(const float* frame_dev, int width, int height, void* stream, int64_t* n_pixels) {
+  if (!frame_dev || !n_pixels || width <= 0 || height <= 0) return fail(EZRT_ERR_INVALID, "bad frame arguments");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* cnt = nullptr;
+  HIP_TRY(hipMalloc((void**)&cnt, sizeof *cnt));
+  hipError_t e = hipMemsetAsync(cnt, 0, sizeof *cnt, st);
+  const size_t n = (size_t)width * (size_t)height;
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(nonfinite_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(frame_dev), n, cnt);
+    e = hipGetLastError();
+  }
+  unsigned long long host = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&host, cnt, sizeof host, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(cnt);
+  if (e != hipSuccess) return fail(EZRT_ERR_DEVICE, "ezrt_frame_nonfinite: %s", hipGetErrorString(e));
+  *n_pixels = (int64_t)host;
+  return 0;
 }
 
 int ezrt_render_paths(EzrtScene* s, const EzrtRenderParams* p, int32_t* tri_id, float* t_hit, float* colour) {
@@ -2582,7 +2365,6 @@ int ezrt_query_hits(EzrtScene* s, const float* rays, int n_rays, int32_t* tri_id
     }
     HIP_TRY(pp.qheads.ensure(QHEADS_WORDS));
     HIP_TRY(hipMemset(pp.qheads.p, 0, QHEADS_WORDS * sizeof(uint32_t)));
-    if (s->tune.xsteal) HIP_TRY(ensure_xs_ring(pp, nullptr));
     HIP_TRY(pp.qcounts.ensure(320));
     HIP_TRY(hipMemset(pp.qcounts.p, 0, 320 * sizeof(uint32_t)));
     const unsigned g1 = (unsigned)((n + 255) / 256);
@@ -2635,7 +2417,7 @@ int ezrt_query_hits(EzrtScene* s, const float* rays, int n_rays, int32_t* tri_id
     t.force_pending = 0u;
     t.wave_log = nullptr;
     HIP_TRY(hipEventRecord(s->ev_trace[0][0], nullptr));
-    if (wide) launch_traceq4_cfg(s, trace_cfg4(s, rel4 != nullptr), t, rel4, nullptr, nullptr, xs_ctl_of(pp), pp.xs_ring.p);
+    if (wide) launch_traceq4_cfg(s, trace_cfg4(s, rel4 != nullptr), t, rel4, nullptr, nullptr);
     else launch_traceq_cfg(s, cfg, t, false, nullptr);
     if (t.steal || wide) {
       TraceQArgs r = t;

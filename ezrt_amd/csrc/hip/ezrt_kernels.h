@@ -356,6 +356,22 @@ __global__ void sobol_kernel(uint32_t index0, int n, int n_dims, float* out) {
   out[i] = sobol((uint32_t)d, gray_code(index0 + (uint32_t)s));
 }
 
+// ezrt_frame_nonfinite: pixels whose running mean is poisoned (the reference's 0/0 in misMixWeight, P5/fsh:754-757, reproduced:
+// include/ezrt.h "Numerical contract").  One ballot per wave, one atomic per wave that saw any.
+__global__ void nonfinite_kernel(const float4* rgba, size_t n, unsigned long long* count) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ((n + 63) & ~(size_t)63); i += (size_t)gridDim.x * blockDim.x) {
+    bool bad = false;
+    if (i < n) {
+      const float4 v = rgba[i];
+      // non-finite = exponent all ones
+      bad = ((__float_as_uint(v.x) & 0x7f800000u) == 0x7f800000u) || ((__float_as_uint(v.y) & 0x7f800000u) == 0x7f800000u) ||
+            ((__float_as_uint(v.z) & 0x7f800000u) == 0x7f800000u);
+    }
+    const unsigned long long m = __ballot(bad);
+    if (m && (threadIdx.x & 63) == 0) atomicAdd(count, (unsigned long long)__popcll(m));
+  }
+}
+
 // pass3.fsh:14-24 + P1/main.cpp:187-189
 __global__ void tonemap_kernel(const float4* rgba, int n, uint8_t* rgb8) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -54,8 +54,9 @@ inline hipError_t stream_acquire(bool high_priority, hipStream_t* out, int* devi
 // alive, 32.2 -> 33.3 with one, -> 31.4 with three, -> 33.4 with three and GPU_MAX_HW_QUEUES=8).  One pair created right after the
 // process's first stream gets two queues of its own and keeps them.  Scenes sharing the pair stay independent: a stream orders the
 // chunks queued to it, nothing in one scene's chunk waits for another scene's.
-// (round 5: the "pair" is SHARED_STREAMS streams -- chunks may be pipelined deeper than two, knob pipeline_depth -- still created together)
-constexpr int SHARED_STREAMS = 4;
+// (round 5 made the pair four streams for deeper pipelines -- measured no gain, and unused streams raise the chance that a chunk stream
+// shares a hardware queue with the caller's in hosts that use torch or RCCL: a pair again since round 6)
+constexpr int SHARED_STREAMS = 2;
 struct SharedPair {
   int device;
   hipStream_t st[SHARED_STREAMS];

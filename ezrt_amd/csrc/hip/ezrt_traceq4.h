@@ -48,22 +48,14 @@
 
 namespace ezd {
 
-// EZRT_SLAB_SELECT = 1: the near / far plane of each axis is SELECTED by the sign of 1/direction -- through the address
-// of the 16-byte row that is loaded -- instead of computed with v_min / v_max of both products.  For a tame ray the
-// two are the same numbers: AA <= BB componentwise, fl(x - S) and fl(. * inv) are monotone, so with inv >= 0 the AA
-// product is the smaller one and with inv < 0 the BB product (equal products: either; +-0 only ever feed
-// comparisons; NaN rows of unused slots stay NaN).  v_min/v_max/v_min3 issue at about half the rate of v_mul/v_sub on
-// gfx950 (profiles/r2/valu_issue_microbench.txt): 24 of them per record become 12 integer address operations.
-// Row order of a record, so that the BB row of an axis lies 64 bytes after its AA row:
-//   select: AAx AAy AAz ref BBx BBy BBz (pad)      min/max: AAx AAy AAz BBx BBy BBz ref (pad)
-#ifndef EZRT_SLAB_SELECT
-#define EZRT_SLAB_SELECT 1
-#endif
-#if EZRT_SLAB_SELECT
+// The near / far plane of each axis is SELECTED by the sign of 1/direction -- through the address of the 16-byte row that is
+// loaded -- instead of computed with v_min / v_max of both products.  For a tame ray the two are the same numbers: AA <= BB
+// componentwise, fl(x - S) and fl(. * inv) are monotone, so with inv >= 0 the AA product is the smaller one and with inv < 0
+// the BB product (equal products: either; +-0 only ever feed comparisons; NaN rows of unused slots stay NaN).
+// v_min/v_max/v_min3 issue at about half the rate of v_mul/v_sub on gfx950 (profiles/r2/valu_issue_microbench.txt): 24 of them
+// per record became 12 integer address operations (round 2: +0.9 % on C2, +2.9 % on C5; the min/max form was removed in round 6).
+// Row order of a record, so that the BB row of an axis lies 64 bytes after its AA row:  AAx AAy AAz ref BBx BBy BBz (pad)
 constexpr int N4_ROW_AA = 0, N4_ROW_BB = 4, N4_ROW_REF = 3;
-#else
-constexpr int N4_ROW_AA = 0, N4_ROW_BB = 3, N4_ROW_REF = 6;
-#endif
 constexpr uint32_t REF_EMPTY = 0xfffffffdu; // unused slot of a 4-wide record
 constexpr int N4_FLOAT4 = 8;                // record stride in HBM, float4s (7 used)
 constexpr int N4_LDS_DWORDS = 28;           // record stride in LDS: 112 B; 28 r mod 64 hits 16 distinct bank quads
@@ -99,14 +91,6 @@ struct TraceQ4Args {
   // cell, direction octant, Morton) is 5-20 % SLOWER than the pipeline's order: mixing cheap and expensive rays in every
   // wave is worth more than coherent memory accesses.  Only the order of processing changes: every ray keeps its slot.
   uint32_t gscat_shift;
-  // Cross-wave work stealing (template parameter XS, knob xsteal; round 5): see "Stealing across waves" below.
-  uint32_t* xs_ctl;            // control words of the scratch set's XS groups, XS_CTL_WORDS each (a 64-byte line of its own per group; zeroed
-                               // per chunk): [0] tail (entries published), [1] head (entries claimed), [2] waves of the group whose queue ran
-                               // dry and that still hold rays, [3] entries a claimer gave up waiting for (must stay 0)
-  unsigned long long* xs_ring; // per group XS_GRING entries of (subtree reference << 32 | ray slot); 0 = empty (zeroed once, re-zeroed by whoever takes an entry)
-  uint32_t xs_gmask;           // groups - 1 (a power of two <= XS_GROUPS_MAX): workgroup b belongs to group b & xs_gmask
-  uint32_t xs_stock;           // entries a group's donors keep published (they stop at this many unclaimed)
-  uint32_t xs_min_idle;        // a wave claims entries only with at least this many idle lanes beyond what its own rich lanes can feed (1 .. 64)
   // Ray hand-over (knob handover; round 5): once the queue is exhausted, an idle lane takes the PREFETCHED ray of a lane that is still
   // traversing -- a whole ray that has not started, handed over in registers (shuffles): no split, no atomic, nothing speculative.
   // Without it the last two rays of a lane (the one it traverses, the one it holds prefetched) run one after the other while the
@@ -114,18 +98,6 @@ struct TraceQ4Args {
   uint32_t handover;
   uint32_t steal_bound;        // a thief (of its own wave) prunes against the victim's best hit so far
 };
-constexpr uint32_t XS_CTL_WORDS = 16;   // control words per group: one 64-byte line
-constexpr uint32_t XS_GROUPS_MAX = 512; // groups per launch at most
-constexpr uint32_t XS_GRING_LOG2 = 12, XS_GRING = 1u << XS_GRING_LOG2; // ring entries per group
-// A donor sees its group's ring one iteration late, so unclaimed entries can exceed xs_stock by what the group's waves publish inside that
-// window: at most XS_GIVE_MAX per wave and iteration -- 7 168 waves in >= 16 groups: 448 x 8 = 3 584 < XS_GRING.  (The first version had ONE
-// ring of 65 536 entries and let a wave publish 64 rows at a time: when the queue ran dry every wave did, 393 216 entries, and the claimers
-// spun on overwritten cells for ever.  The second version bounded that and was 30 x SLOWER than no stealing at all: every wave polled ONE
-// control line every iteration, and a line serves ~100 agent-scope reads per microsecond -- an iteration took 100 us.  Hence groups: a
-// control line is polled by the 24-28 waves of its group only.)
-constexpr uint32_t XS_GIVE_MAX = 8;
-constexpr uint32_t XS_BUSY = 2, XS_ERR = 3;
-
 // ---- Distance pruning (PRUNE > 0): results-neutral, proven, not merely observed.
 //
 // The reference's hitBVH never prunes (P5/fsh:254-306), so the result of a ray is the minimum of t over every triangle
@@ -215,13 +187,6 @@ EZD void chunk_prologue(const ChunkPrologue& g, uint32_t tid, uint32_t n_threads
 // launch read them there: recomputing the direction in the shading kernels cost them 30 us each on C2, more than the
 // 16-byte read).  What goes away is raygen_kernel's launch and this kernel's read of the queue: the stores ride on a
 // memory system the VALU-bound traversal leaves idle.
-//
-// Hook: what happens to a lane whose ray is finished.  NoPathHook (traceq4_kernel): the hit record is published and the
-// lane takes the next ray of the queue.  A path hook (pathq4_kernel, ezrt_wavefront.h) shades the hit IN the refill block
-// and hands the lane the path's next ray, so that the small late bounces of a chunk are ONE launch whose length is the
-// longest path's, not one launch per bounce each as long as its deepest ray; exact ties and rays that are not tame are
-// then re-traced in the reference's order by the lane itself (hook.retrace), and there is no stealing (a split ray
-// would need a completion count before it can be shaded).
 // Which of two triangles with the SAME hit distance does the reference's hitBVH keep?  The first one it finds (strict <,
 // P5/fsh:247, 274), i.e. the one whose leaf comes first in its depth-first order: near child first at every node, ties
 // right-first (P5/fsh:291-298).  Two leaves are ordered at their lowest common ancestor alone -- the whole subtree of the
@@ -255,44 +220,12 @@ EZD bool tie_precedes(const TraceQ4Args& A, int32_t tri_a, int32_t tri_b, f3 S, 
   return ((uint32_t)ua.y >> 31) ? !left_first : left_first;
 }
 
-struct NoPathHook {
-  static constexpr bool PATH = false;
-  EZD void retrace(f3, f3, int*, int32_t&, float&) const {}
-  EZD bool shade(uint32_t, f3&, f3&, int32_t, float, int&) const { return false; }
-  EZD int first_bounce() const { return 0; }
-};
 // SEMI: rays with an exactly-zero direction component are traversed here (with the NaN watch) instead of sent to the redo
 // list.  A template parameter because the watch costs every ray of the launch 2-3 % (a ballot per iteration, four flags,
 // registers); the host turns it on for the launches that see such rays in numbers: the MIS integrators' bounce stages.
-// ---- Stealing across waves (XS; round 5).  A launch used to last as long as its slowest WAVE: the queue runs dry for
-// everybody at about the same time, and from then on a wave can only spread its last rays over its own 64 lanes (the intra-wave
-// stealing above) while the waves that drew cheap rays have retired -- C2's primary stage has its median wave done at 593 us and its
-// last at 749, the 1/8 shard of a frame at 66 and 291.  With XS the pending subtrees cross wave boundaries inside a GROUP of workgroups
-// (workgroup b belongs to group b & xs_gmask: 256 groups of 6-7 workgroups by default) through the group's ring in global memory:
-//  * DONOR: a wave whose queue is exhausted and that has more lanes with pending stack rows than idle lanes of its own publishes
-//    the surplus lanes' OLDEST row (the bottom of the stack: the largest subtree) while fewer than xs_stock of the group's entries
-//    are unclaimed: one atomicAdd on the group's tail reserves the positions, the ray is marked split exactly as for a thief of its
-//    own wave (record reset to "no hit yet", 64-bit atomicMin merges from then on) and its best hit so far is merged at once -- the
-//    thief prunes against it -- then, behind an s_waitcnt, one 8-byte agent-scope store per entry: (reference << 32 | slot), never 0.
-//  * THIEF: a wave with more idle lanes than rich ones claims entries of its group with ONE compare-and-swap on the head (the tail
-//    only grows, so head unchanged means the claimed positions are published or about to be: the entry is polled until it is non-zero,
-//    then zeroed for the ring's next lap).  It reads nothing another wave wrote in this launch except through agent-scope atomics:
-//    the ray comes from the queue the PREVIOUS kernel wrote (or is re-generated: GEN), the bound from the hit record.
-//  * a wave with nothing at all waits for entries of its group (s_sleep between polls) as long as some wave of the group that ran
-//    dry still holds rays (the group's XS_BUSY word); otherwise it retires.
-// No entry is ever lost: a wave only publishes into its own group's ring and only retires after it has SEEN that ring's tail == head
-// later than its own last donation; the head passes a position only by claiming it, and whoever claims an entry traverses it before
-// it retires in turn.  No wave waits for a wave that has not started: waiting depends on a count that only running waves raise, so a
-// grid that is not fully resident (a pipelined chunk's) cannot deadlock; retiring early only loses parallelism.  Every wait is
-// bounded (a protocol error must show as a wrong image and a non-zero XS_ERR word, not as a hung device).  Results: the merge is
-// the minimum of the same triangle set whoever traverses which subtree; pruning against a hit some contributor HAS found is the
-// proven bound (the final minimum is no larger); exact ties between contributors go to the redo list as before.  Visibility
-// (MI355X_MICROARCH.md "inter-workgroup visibility": the XCDs' L2s are not coherent): every word two waves share is only touched
-// by agent-scope atomics.  Polling: a group's control line is read by its own waves only, once per iteration each.
-template <bool REL, bool LOG, int PRUNE, bool GEN, class Hook, bool SEMI = false, bool GS = false, bool XS = false>
-EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
+template <bool REL, bool LOG, int PRUNE, bool GEN, bool SEMI = false, bool GS = false>
+EZD void traceq4_body(const TraceQ4Args& A) {
   static_assert(!GEN || REL, "generated rays start at the launch's uniform origin");
-  static_assert(!XS || !Hook::PATH, "a path kernel shades in the refill block: its rays are never split");
   extern __shared__ __attribute__((aligned(16))) int lds_stack[];
   const TraceQArgs& a = A.q;
   // LDS layout: [lane table: BLOCK ints][stack rows][staged records]
@@ -304,7 +237,7 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
   // (GSCAT: queue positions below are LOGICAL; see TraceQ4Args::gscat_shift.  The logical domain is 256 * R whole granules.)
   // (granule = 8 slots, a compile-time constant, and R is re-derived from n_rays where it is used: the kernel sits at its
   // SGPR limit too, and every uniform value kept across the loop is spilled into a VGPR lane)
-  constexpr bool gscat = GS && !GEN && !Hook::PATH;
+  constexpr bool gscat = GS && !GEN;
   constexpr uint32_t GSH = 3u;
   const uint32_t n_rays = gscat ? ((((n_real + (1u << GSH) - 1u) >> GSH) + 255u) >> 8) << (8u + GSH) : n_real;
   int* wsrc = lds_stack + (threadIdx.x >> 6) * 64;
@@ -340,7 +273,6 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
   bool anyhit = false;  // an env shadow ray: any accepted hit ends the traversal (TraceQArgs::anyhit_even)
   uint32_t ref = REF_NONE;
   uint32_t n_counted = 0;
-  int bl = 0; // (Hook::PATH) the bounce this lane's path is in
   unsigned long long* hits64 = reinterpret_cast<unsigned long long*>(a.hits);
   // PRUNE: a slot is skipped when its entry distance exceeds prune_t = (best_t + pdelta)(1 + 2^-19),
   //   pdelta = (prune_a + prune_cs |S|_inf) max_k |inv_k|
@@ -395,96 +327,6 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
     }
   };
 
-  // ---- XS: stealing across waves (see the comment above this function)
-  const bool xs_on = XS && A.xs_ctl != nullptr && a.steal != 0u; // (wave-uniform; the knob is a launch argument)
-  const uint32_t xs_group = XS ? (blockIdx.x & A.xs_gmask) : 0u;
-  uint32_t* const xs_g = A.xs_ctl + (size_t)xs_group * XS_CTL_WORDS;            // this wave's group: control words ...
-  unsigned long long* const xs_gring = A.xs_ring + (size_t)xs_group * XS_GRING; // ... and ring (never touched unless xs_on)
-  unsigned long long xs_seen = 0ull; // the group's control word {tail, head | << 32} as loaded during the previous iteration
-  uint32_t xs_polls = 0u;            // polls of a waiting wave without work
-  bool xs_counted = false;           // this wave is counted in its XS_BUSY word
-  uint32_t dbg_xs_give = 0, dbg_xs_take = 0;
-  auto xs_ctl64 = [&]() { return __hip_atomic_load(reinterpret_cast<unsigned long long*>(xs_g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  auto xs_adopt = [&](unsigned long long e) { // this lane traverses the published subtree e = (reference << 32 | slot) for that slot's ray
-    slot = (uint32_t)e;
-    float4 vd;
-    if (GEN) vd = primary_dir(A.gen_p, A.gen_blocks, A.gen_div_blocks, A.gen_div_sub, A.gen_scatter, A.gen_scatter_shift, A.gen_frame_first, slot);
-    else vd = a.rq.d[slot]; // (written by the kernel before this one; GEN: the owner's store may still sit in another XCD's L2)
-    if (REL || a.const_origin == 1u) {
-      S = mk(a.origin[0], a.origin[1], a.origin[2]);
-    } else {
-      const float4 vo = a.rq.o[slot >> (a.const_origin >> 1)];
-      S = mk(vo.x, vo.y, vo.z);
-    }
-    d = mk(vd.x, vd.y, vd.z);
-    inv = mk(ez_rcp(d.x), ez_rcp(d.y), ez_rcp(d.z));
-    best_t = INF;
-    best_tri = -1;
-    sp = 0;
-    sb = 0;
-    tie = false;
-    tie_tri = -1;
-    shared = true;
-    semi = SEMI && ray_is_semi(S, d, inv);
-    anyhit = a.anyhit_even != 0u && (slot & 1u) == 0u;
-    ref = (uint32_t)(e >> 32);
-    if (PRUNE) set_delta();
-    // what the ray's other contributors have found so far (the donor merged its best hit before it published the entry): a real
-    // hit of THIS ray, so the final minimum is no larger and the proven margin applies to it
-    const unsigned long long h = __hip_atomic_load(&hits64[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (h != ~0ull) {
-      if (PRUNE) prune_t = hw_min(prune_t, (__uint_as_float((uint32_t)(h >> 32)) + pdelta) * PRUNE_REL);
-      if (anyhit && (int32_t)(uint32_t)h >= 0) finish(); // (an env shadow ray that has hit something is done)
-    }
-  };
-  // claim `want` (>= 1, wave-uniform) published entries for the lanes with taker && trank < want; `head` = the head value the
-  // availability was computed from (tail - head >= want then, and the tail only grows)
-  auto xs_claim = [&](uint32_t head, uint32_t want, bool taker, uint32_t trank) -> bool {
-    uint32_t ok = 0u;
-    if (lane == 0) ok = atomicCAS(xs_g + 1, head, head + want) == head ? 1u : 0u;
-    ok = (uint32_t)__builtin_amdgcn_readfirstlane((int)ok);
-    if (!ok) return false;
-    if (taker && trank < want) {
-      unsigned long long* cell = xs_gring + ((head + trank) & (XS_GRING - 1u));
-      unsigned long long e;
-      uint32_t tries = 0u;
-      do { // (the donor reserved the position before it stored the entry: a store away at most.  Bounded all the same: a
-           // protocol error must show as a wrong image and a non-zero XS_ERR word, not as a hung device)
-        e = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } while (e == 0ull && ++tries < (1u << 18));
-      if (e != 0ull) {
-        __hip_atomic_store(cell, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        xs_adopt(e);
-      } else {
-        atomicAdd(xs_g + XS_ERR, 1u);
-      }
-    }
-    if (LOG && a.wave_log) dbg_xs_take += want;
-    return true;
-  };
-  // publish the oldest pending row of the lanes with donor && drank < n_give (n_give >= 1, wave-uniform)
-  auto xs_donate = [&](uint32_t n_give, bool donor, uint32_t drank) {
-    uint32_t base = 0u;
-    if (lane == 0) base = atomicAdd(xs_g, n_give);
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    const bool dn = donor && drank < n_give;
-    int give = 0;
-    if (dn) {
-      give = stack[sb * BLOCK];
-      sb++;
-      if (!shared) atomicExch(&hits64[slot], ~0ull); // first split: "no hit yet"
-      shared = true;
-      if (best_tri >= 0) atomicMin(&hits64[slot], ((unsigned long long)__float_as_uint(best_t) << 32) | (uint32_t)best_tri);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the record is reset (and holds this lane's best) before anybody can see the entry
-    if (dn)
-      __hip_atomic_store(xs_gring + ((base + drank) & (XS_GRING - 1u)), ((unsigned long long)(uint32_t)give << 32) | slot, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-    if (LOG && a.wave_log) dbg_xs_give += n_give;
-  };
-  uint32_t* const xs_busy_word = xs_g + XS_BUSY;
-  bool xs_retire = false;
-
   const unsigned long long t_start = (LOG && a.wave_log) ? wall_clock64() : 0ull;
   unsigned long long t_exhausted = 0ull; // (debug_stages=2) when this wave first found the queue empty
   uint32_t wave_iters = 0, dbg_inner_lanes = 0, dbg_inner_steps = 0, dbg_leaf_lanes = 0, dbg_leaf_rounds = 0, dbg_busy_lanes = 0,
@@ -496,30 +338,7 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
     const unsigned long long wantm = ballot(want);
     if (wantm && ((uint32_t)__popcll(wantm) >= a.refill_min || !ballot(ref < REF_DONE))) {
       if (LOG && a.wave_log) dbg_refills++;
-      if (Hook::PATH) {
-        if (ref == REF_DONE) {
-          if (tie_tri >= 0 && !tie && tie_precedes(A, tie_tri, best_tri, S, inv)) best_tri = tie_tri;
-          tie_tri = -1;
-          if (tie) hook.retrace(S, d, stack, best_tri, best_t); // a third tied candidate / not tame: the reference's order, in this lane
-          tie = false;
-          if (hook.shade(slot, S, d, best_tri, best_t, bl)) { // the path goes on: S, d = its next ray
-            n_counted += a.count_rays;
-            inv = mk(ez_rcp(d.x), ez_rcp(d.y), ez_rcp(d.z));
-            best_t = INF;
-            best_tri = -1;
-            sp = 0;
-            sb = 0;
-            semi = SEMI && ray_is_semi(S, d, inv);
-            tie = !(ray_is_tame(S, inv) || semi);
-            ref = tie ? REF_DONE : A.root4; // (a ray that is not tame is "finished" at once and re-traced at the next refill)
-            if (PRUNE) set_delta();
-          } else {
-            ref = REF_NONE;
-          }
-        }
-      } else if (ref == REF_DONE) {
-        publish();
-      }
+      if (ref == REF_DONE) publish();
       if (ref == REF_NONE && nx_slot != REF_NONE) {
         const uint32_t adopted = nx_slot;
         nx_slot = REF_NONE;
@@ -543,7 +362,6 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
           tie_tri = -1;
           ref = tie ? REF_DONE : A.root4;
           best_tri = tie ? HIT_PENDING : -1;
-          if (Hook::PATH) bl = hook.first_bounce();
           if (PRUNE) set_delta();
         }
       }
@@ -604,23 +422,13 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
       // scattered draw a whole pool can fall into the padding past the queue's end (rs >= n_real) while later static
       // rounds still hold rays (pool_max 8 with static_pct 50 left 96 of 400 000 rays untraced)
       if (!exhausted) continue;
-      if (!xs_on) break;
-      // (XS) the steal block below claims subtrees other waves published, waits for some, or retires the wave
-      if (xs_counted) {
-        if (lane == 0) atomicSub(xs_busy_word, 1u);
-        xs_counted = false;
-      }
-    } else if (xs_on && exhausted) {
-      if (!xs_counted) { // from now on this wave may publish: waiting waves stay while any such wave holds rays
-        if (lane == 0) atomicAdd(xs_busy_word, 1u);
-        xs_counted = true;
-      }
+      break;
     }
     if (LOG && a.wave_log && exhausted && !t_exhausted) t_exhausted = wall_clock64();
 
     // ---- work stealing: lanes with nothing left to fetch take the oldest pending subtree of a busy lane
     if (a.steal && exhausted) {
-      if (A.handover && !Hook::PATH) { // idle lanes take the prefetched rays of lanes that are still traversing (see TraceQ4Args::handover)
+      if (A.handover) { // idle lanes take the prefetched rays of lanes that are still traversing (see TraceQ4Args::handover)
         const bool idle0 = (ref & nx_slot) == REF_NONE;
         const bool host = nx_slot != REF_NONE && ref < REF_DONE;
         const unsigned long long im0 = ballot(idle0), hm = ballot(host);
@@ -647,7 +455,7 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
       }
       const bool idle = (ref & nx_slot) == REF_NONE;
       const unsigned long long im = ballot(idle);
-      if (im || xs_on) {
+      if (im) {
         const bool rich = sp > sb;
         const unsigned long long vm = ballot(rich);
         const int ni = (int)__popcll(im), nv = (int)__popcll(vm);
@@ -693,40 +501,8 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
             if (PRUNE) prune_t = hw_min(prune_t, (vbt + pdelta) * PRUNE_REL);
           }
         }
-        if (xs_on && ni != nv) { // a surplus of pending rows, or of idle lanes: the business of the group's other waves too
-          const bool all_idle = ni == 64; // (nothing else to do: look at the ring now, not at what the last iteration saw)
-          if (all_idle) xs_seen = xs_ctl64();
-          const uint32_t tail = (uint32_t)xs_seen, head = (uint32_t)(xs_seen >> 32);
-          const int avail = (int)(tail - head);
-          if (nv > ni) {
-            if (avail < (int)A.xs_stock) {
-              int k = nv - ni;
-              const int room = (int)A.xs_stock - avail;
-              k = k < room ? k : room;
-              k = k < (int)XS_GIVE_MAX ? k : (int)XS_GIVE_MAX;
-              xs_donate((uint32_t)k, rich && vr >= n, (uint32_t)(vr - n));
-            }
-          } else if (avail > 0) {
-            // (a claim stalls the whole wave for a few memory round trips -- the head, the entry, the ray, the hit record: worth
-            // it for a wave that is mostly idle, not for one that would fill two lanes and hold up sixty)
-            if (ni - nv >= (int)A.xs_min_idle) {
-              if (!xs_claim(head, (uint32_t)(ni - nv < avail ? ni - nv : avail), idle && ir >= n, (uint32_t)(ir - n)) && all_idle)
-                __builtin_amdgcn_s_sleep(4); // (lost the race for the head)
-              xs_polls = 0u;
-            }
-          } else if (all_idle) {
-            // nothing published and nothing of its own: the wave waits while some wave of its group that ran dry still holds rays
-            // (not for ever), else it retires -- having just SEEN tail == head, later than its own last donation
-            uint32_t b = __hip_atomic_load(xs_busy_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-            if (b == 0u || ++xs_polls > 4096u) xs_retire = true;
-            else __builtin_amdgcn_s_sleep(32);
-          }
-          if (!all_idle && (nv > ni || ni - nv >= (int)A.xs_min_idle)) xs_seen = xs_ctl64(); // (used in the next iteration: nobody waits for it here)
-        }
       }
     }
-    if (XS && xs_retire) break;
 
     // ---- inner step: four slab tests (hitAABB, P5/fsh:220-233) on one 4-wide record
     const bool at_inner = (int32_t)ref >= 0;
@@ -739,7 +515,6 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
     if (at_inner) {
       typedef float v4f __attribute__((ext_vector_type(4)));
       typedef __attribute__((address_space(3))) const v4f lds_v4f;
-#if EZRT_SLAB_SELECT
       typedef __attribute__((address_space(3))) const char lds_char;
       // byte offset of the NEAR row of each axis inside a record: 0 (AA) for inv >= 0, 64 (BB) for inv < 0
       const uint32_t kx = (__float_as_uint(inv.x) >> 31) << 6, ky = (__float_as_uint(inv.y) >> 31) << 6,
@@ -797,49 +572,6 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
       const bool h1 = slab(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, e1, n1);
       const bool h2 = slab(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, e2, n2);
       const bool h3 = slab(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, e3, n3);
-#else
-      const bool wave_semi = false, n0 = false, n1 = false, n2 = false, n3 = false;
-      static_assert(PRUNE == 0, "distance pruning is implemented on the EZRT_SLAB_SELECT form of the slab test");
-      const float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f, e3 = 0.0f;
-      float4 ax, ay, az, bx, by, bz, rf;
-      if (ref < (uint32_t)A.lds_nodes4) { // top of the tree: staged in LDS
-        lds_v4f* r = (lds_v4f*)(lds_nodes + ref * 7u);
-        const v4f w0 = r[0], w1 = r[1], w2 = r[2], w3 = r[3], w4 = r[4], w5 = r[5], w6 = r[6];
-        ax = make_float4(w0.x, w0.y, w0.z, w0.w);
-        ay = make_float4(w1.x, w1.y, w1.z, w1.w);
-        az = make_float4(w2.x, w2.y, w2.z, w2.w);
-        bx = make_float4(w3.x, w3.y, w3.z, w3.w);
-        by = make_float4(w4.x, w4.y, w4.z, w4.w);
-        bz = make_float4(w5.x, w5.y, w5.z, w5.w);
-        rf = make_float4(w6.x, w6.y, w6.z, w6.w);
-      } else {
-        const float4* r = inner + (size_t)ref * N4_FLOAT4;
-        ax = r[0];
-        ay = r[1];
-        az = r[2];
-        bx = r[3];
-        by = r[4];
-        bz = r[5];
-        rf = r[6];
-      }
-      auto slab = [&](float axk, float ayk, float azk, float bxk, float byk, float bzk) -> bool {
-        float fx, fy, fz, nx, ny, nz;
-        if (REL) { // boxes already translated by the common origin
-          fx = bxk * inv.x, fy = byk * inv.y, fz = bzk * inv.z;
-          nx = axk * inv.x, ny = ayk * inv.y, nz = azk * inv.z;
-        } else {
-          fx = (bxk - S.x) * inv.x, fy = (byk - S.y) * inv.y, fz = (bzk - S.z) * inv.z;
-          nx = (axk - S.x) * inv.x, ny = (ayk - S.y) * inv.y, nz = (azk - S.z) * inv.z;
-        }
-        const float t1 = hw_min3(hw_max(fx, nx), hw_max(fy, ny), hw_max(fz, nz));
-        const float t0 = hw_max3(hw_min(fx, nx), hw_min(fy, ny), hw_min(fz, nz));
-        return (t1 >= t0) && (t1 > 0.0f); // == hitAABB(..) > 0
-      };
-      const bool h0 = slab(ax.x, ay.x, az.x, bx.x, by.x, bz.x);
-      const bool h1 = slab(ax.y, ay.y, az.y, bx.y, by.y, bz.y);
-      const bool h2 = slab(ax.z, ay.z, az.z, bx.z, by.z, bz.z);
-      const bool h3 = slab(ax.w, ay.w, az.w, bx.w, by.w, bz.w);
-#endif
       const uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z),
                      r3 = __float_as_uint(rf.w);
       // (unused slots hold NaN boxes on purpose: only a NaN in a USED slot means 0 x inf)
@@ -986,17 +718,16 @@ EZD void traceq4_body(const TraceQ4Args& A, const Hook& hook) {
     w[2] = wave_iters | ((unsigned long long)dbg_inner_steps << 32);
     w[3] = rr | ((unsigned long long)dbg_inner_lanes << 32);
     w[4] = dbg_leaf_lanes | ((unsigned long long)dbg_leaf_rounds << 32);
-    w[5] = dbg_busy_lanes | ((unsigned long long)(dbg_xs_give & 0xffffu) << 32) | ((unsigned long long)(dbg_xs_take & 0xffffu) << 48);
+    w[5] = dbg_busy_lanes;
     w[6] = dbg_refills | ((unsigned long long)dbg_steals << 32);
     w[7] = t_exhausted;
   }
 }
 
 // GS: queue positions are drawn in the scattered order (TraceQ4Args::gscat_shift; granules of 8 slots)
-// XS: subtrees are stolen across waves (TraceQ4Args::xs_ctl)
-template <int WPS, bool REL, bool LOG = false, int PRUNE = 0, bool GEN = false, bool SEMI = false, bool GS = false, bool XS = false>
+template <int WPS, bool REL, bool LOG = false, int PRUNE = 0, bool GEN = false, bool SEMI = false, bool GS = false>
 __global__ __launch_bounds__(BLOCK, WPS) void traceq4_kernel(TraceQ4Args A) {
-  traceq4_body<REL, LOG, PRUNE, GEN, NoPathHook, SEMI, GS, XS>(A, NoPathHook());
+  traceq4_body<REL, LOG, PRUNE, GEN, SEMI, GS>(A);
 }
 
 } // namespace ezd

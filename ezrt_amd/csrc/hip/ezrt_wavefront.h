@@ -179,7 +179,7 @@ struct ShadeOut {
 // is still alive returns true ("deferred") and touches nothing.  PASS 2: the deferred paths, regrouped
 // densely by the caller.  Bounce rays mostly leave the scene (90 % on C2), so without the regrouping
 // every wave ran the ~700-instruction surface code for a handful of its lanes.
-struct ShadeIn { // what stage b reads for one path (from the queues, or from registers in tail_kernel)
+struct ShadeIn { // what stage b reads for one path (from the queues)
   float4 rd4, ro4, s0, s1, s2, s3, s4;
   int2 h, sh;
 };
@@ -259,15 +259,14 @@ EZD void shade_load(const WfArgs& a, const uint32_t i, const bool live, ShadeIn&
 }
 
 // `i` is only used by stage 0 (queue position -> sample slot)
-// b_lane (>= 0): the bounce index of THIS path when the kernel's paths are not all at a.bounce (pathq4_kernel)
 template <int INTEG, bool FULLCTR, int PASS, int STAGE>
 EZD bool shade_body(const WfArgs& a, const uint32_t i, bool live, const ShadeIn& in, Counters& ctr, uint32_t& n_samples,
-                    ShadeOut& o, const int b_lane = -1) {
+                    ShadeOut& o) {
   constexpr bool P5TRI = (INTEG >= 50);
   constexpr bool MIS = integ_mis<INTEG>();
   const DevScene& sc = a.sc;
   const EzrtRenderParams& p = a.p;
-  const int b = b_lane >= 0 ? b_lane : a.bounce;
+  const int b = a.bounce;
   constexpr bool B0 = (STAGE == 0);
   constexpr bool COMPACT = compact_state<INTEG>();
   uint32_t sslot = 0, seed = 0, flags = 0, tri0 = 0;
@@ -684,152 +683,6 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void shade_kernel(WfArgs a) {
       atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_ENV_CACHE], v6);
     }
   }
-}
-
-// ---------------------------------------------------------------------------
-// pathq4_kernel: the bounces >= a.bounce of a chunk as ONE persistent launch (integrators without MIS: one ray per path).
-//
-// After two stages only a few per cent of a chunk's paths are alive (C2: 0.7 M of 16.8 M enter stage 2) and a stage costs
-// its fixed price, not its work: a trace launch lasts as long as its DEEPEST ray (iterations of ~2-3 us each, whatever the
-// queue holds), then a redo launch, then a shading launch, each behind a launch gap -- stages 2-4 were 450 of C2's 2200 us
-// for 4 % of its rays.  Here the traversal is traceq4_body itself (4-wide records, pruning, cooperative leaves, prefetched
-// refill); a lane whose ray is finished is shaded in the refill block by the staged kernels' own shade_body and continues
-// with the path's next ray, its state parked in the stage's state arrays at the path's queue index.  One launch, one tail:
-// the longest PATH.  Exact ties and rays that are not tame are re-traced by the lane in the reference's order (hit_bvh).
-// Same arithmetic per path as the staged kernels, so the same samples; rays are counted into the same counter.
-// MEASURED (C2, profiles/r3/path_kernel_negative.txt): NOT faster -- 800-1000 us against the staged stages' 450 us.  The
-// premise fails: the longest path is about the SUM of the stages' deepest rays (a path in a concavity of the Bunny stays
-// deep bounce after bounce), and each shading batch stalls the live traversals of its wave for its chain of dependent
-// loads.  Off by default (Tuning::path_stage), kept with its tests as the measured end of that idea.
-template <int INTEG>
-struct PathHook {
-  static constexpr bool PATH = true;
-  const WfArgs& w;
-  EZD int first_bounce() const { return w.bounce; }
-  EZD void retrace(f3 S, f3 d, int* stack, int32_t& best_tri, float& best_t) const {
-    Counters dummy = {0, 0, 0, 0, 0, 0, 0};
-    hit_bvh<false, BLOCK>(w.sc, S, d, stack, best_tri, best_t, dummy);
-  }
-  // slot: the path's index in the stage's queue = where its state lives.  Returns true if the path goes on (S, d = next ray).
-  EZD bool shade(uint32_t slot, f3& S, f3& d, int32_t best_tri, float best_t, int& bl) const {
-    constexpr bool COMPACT = compact_state<INTEG>();
-    ShadeIn in;
-    in.rd4 = make_float4(d.x, d.y, d.z, 1.0f);
-    in.ro4 = make_float4(S.x, S.y, S.z, 0.0f);
-    in.s0 = w.st_in.s0[slot];
-    in.s1 = w.st_in.s1[slot];
-    in.s2 = w.st_in.s2[slot];
-    in.s3 = COMPACT ? make_float4(0, 0, 0, 0) : w.st_in.s3[slot];
-    in.s4 = make_float4(0, 0, 0, 0);
-    in.h = make_int2(best_tri, __float_as_int(best_t));
-    in.sh = make_int2(-1, 0);
-    Counters ctr = {0, 0, 0, 0, 0, 0, 0};
-    uint32_t ns = 0;
-    ShadeOut o;
-    shade_body<INTEG, false, 0, 2>(w, slot, true, in, ctr, ns, o, bl);
-    if (!o.emit) return false;
-    if (COMPACT) {
-      w.st_in.s0[slot] = make_float4(o.history.x, o.history.y, o.history.z, o.cosine);
-      w.st_in.s1[slot] = make_float4(o.Lo.x, o.Lo.y, o.Lo.z, __uint_as_float(o.sslot));
-      w.st_in.s2[slot] = make_float4(o.f_r.x, o.f_r.y, o.f_r.z, __uint_as_float(o.tri0));
-    } else {
-      w.st_in.s0[slot] = make_float4(o.history.x, o.history.y, o.history.z, o.cosine);
-      w.st_in.s1[slot] = make_float4(o.Lo.x, o.Lo.y, o.Lo.z, o.pdf);
-      w.st_in.s2[slot] = make_float4(o.f_r.x, o.f_r.y, o.f_r.z, __uint_as_float(o.sslot));
-      w.st_in.s3[slot] = make_float4(o.Le0.x, o.Le0.y, o.Le0.z, __uint_as_float(o.seed));
-    }
-    S = o.P;
-    d = o.rayL;
-    bl++;
-    return true;
-  }
-};
-template <int INTEG, int PRUNE>
-__global__ __launch_bounds__(BLOCK, 4) void pathq4_kernel(TraceQ4Args A, WfArgs W) {
-  static_assert(!integ_mis<INTEG>(), "one ray per path");
-  const PathHook<INTEG> hook{W};
-  traceq4_body<false, false, PRUNE, false>(A, hook);
-}
-
-// ---------------------------------------------------------------------------
-// tail_kernel: everything after stage `a.bounce` for the paths of its queue, one lane per path.
-//
-// After two or three stages only a few per cent of the paths are alive (C2: 0.7 M of 16.8 M enter stage 2), and
-// a stage then costs its fixed price -- four dependent launches, each draining the chip, and persistent trace
-// waves that issue full-width instructions for a handful of live lanes -- not its work: stages 2-4 were 17 % of
-// a C2 step for 4 % of its rays.  Here a lane keeps its path in registers and alternates hitBVH (in the
-// reference's visit order: hit_bvh of ezrt_device.h, so there are no ties to redo) with the stage's shading
-// (shade_body, the same code the staged kernels run) until the path ends.  Same arithmetic per path, so the same
-// samples; ray counts are added to the same counters.
-template <int INTEG>
-__global__ __launch_bounds__(BLOCK) void tail_kernel(WfArgs a, int32_t stack_entries) {
-  extern __shared__ __attribute__((aligned(16))) int lds_stack[];
-  constexpr bool MIS = integ_mis<INTEG>();
-  constexpr bool COMPACT = compact_state<INTEG>();
-  (void)stack_entries;
-  const DevScene& sc = a.sc;
-  const uint32_t n_in = *a.n_in;
-  int* stack = lds_stack + threadIdx.x;
-  Counters ctr = {0, 0, 0, 0, 0, 0, 0};
-  uint32_t n_samples = 0;
-  const int b0 = a.bounce;
-  for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_in; i += gridDim.x * BLOCK) {
-    // the path as the stage-b0 kernels would read it, except that its rays have not been traced yet
-    ShadeIn in;
-    const uint32_t rslot = MIS ? 2u * i + 1u : i;
-    in.rd4 = a.rq_in.d[rslot];
-    in.ro4 = a.rq_in.o[i];
-    in.s0 = a.st_in.s0[i];
-    in.s1 = a.st_in.s1[i];
-    in.s2 = a.st_in.s2[i];
-    in.s3 = COMPACT ? make_float4(0, 0, 0, 0) : a.st_in.s3[i];
-    in.s4 = make_float4(0, 0, 0, 0);
-    float4 sd4 = make_float4(0, 0, 0, 0); // shadow ray (MIS)
-    if (MIS) {
-      in.s4 = a.st_in.s4[i];
-      sd4 = a.rq_in.d[2u * i];
-    }
-    WfArgs w = a;
-    for (int b = b0;; b++) {
-      const f3 O = mk(in.ro4.x, in.ro4.y, in.ro4.z);
-      in.h = make_int2(-1, 0);
-      in.sh = make_int2(-1, 0);
-      if (MIS && sd4.w != 0.0f) {
-        int32_t tri;
-        float t;
-        hit_bvh<false, BLOCK>(sc, O, mk(sd4.x, sd4.y, sd4.z), stack, tri, t, ctr);
-        in.sh = make_int2(tri, __float_as_int(t));
-      }
-      if (in.rd4.w != 0.0f) {
-        int32_t tri;
-        float t;
-        hit_bvh<false, BLOCK>(sc, O, mk(in.rd4.x, in.rd4.y, in.rd4.z), stack, tri, t, ctr);
-        in.h = make_int2(tri, __float_as_int(t));
-      }
-      w.bounce = b;
-      ShadeOut o;
-      shade_body<INTEG, false, 0, 2>(w, i, true, in, ctr, n_samples, o);
-      if (!o.emit) break;
-      // what shade_store would have queued for stage b + 1
-      const bool shoot = !(o.flags & FLAG_TERMINATE);
-      in.ro4 = make_float4(o.P.x, o.P.y, o.P.z, 0.0f);
-      in.rd4 = make_float4(o.rayL.x, o.rayL.y, o.rayL.z, (!MIS || shoot) ? 1.0f : 0.0f);
-      if (MIS) sd4 = make_float4(o.shadowL.x, o.shadowL.y, o.shadowL.z, (o.flags & FLAG_SHADOW_SHOT) ? 1.0f : 0.0f);
-      if (COMPACT) {
-        in.s0 = make_float4(o.history.x, o.history.y, o.history.z, o.cosine);
-        in.s1 = make_float4(o.Lo.x, o.Lo.y, o.Lo.z, __uint_as_float(o.sslot));
-        in.s2 = make_float4(o.f_r.x, o.f_r.y, o.f_r.z, __uint_as_float(o.tri0));
-      } else {
-        in.s0 = make_float4(o.history.x, o.history.y, o.history.z, o.cosine);
-        in.s1 = make_float4(o.Lo.x, o.Lo.y, o.Lo.z, o.pdf);
-        in.s2 = make_float4(o.f_r.x, o.f_r.y, o.f_r.z, __uint_as_float(o.sslot));
-        in.s3 = make_float4(o.Le0.x, o.Le0.y, o.Le0.z, __uint_as_float(o.seed));
-        in.s4 = make_float4(o.shadowC.x, o.shadowC.y, o.shadowC.z, __uint_as_float(o.flags));
-      }
-    }
-  }
-  const unsigned long long rr = wave_sum(ctr.rays);
-  if ((threadIdx.x & 63) == 0 && rr) atomicAdd(&ctr_slot(a.counters)[EZRT_CTR_RAYS], rr);
 }
 
 // ---------------------------------------------------------------------------

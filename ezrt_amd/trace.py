@@ -210,6 +210,14 @@ class TraceLib:
     def frame(self, width, height):
         return Frame(self, width, height)
 
+    def frame_nonfinite(self, frame_ptr, width, height, stream=None):
+        """ezrt_frame_nonfinite: pixels of a device-resident RGBA32F frame with a non-finite R, G or B."""
+        n = C.c_int64()
+        if self.lib.ezrt_frame_nonfinite(C.c_void_p(frame_ptr), int(width), int(height), C.c_void_p(stream or 0),
+                                         C.cast(C.byref(n), _abi.c_int64_p)) != 0:
+            raise TraceError(self.lib.ezrt_last_error().decode())
+        return int(n.value)
+
     def trim(self):
         """ezrt_trim: destroy the streams parked by destroyed scenes; returns how many."""
         return int(self.lib.ezrt_trim())

@@ -137,6 +137,11 @@ int ezrt_frame_create(int width, int height, float** frame_dev);
 int ezrt_frame_destroy(float* frame_dev);
 int ezrt_frame_read(const float* frame_dev, int width, int height, float* rgba_host);
 int ezrt_frame_write(float* frame_dev, int width, int height, const float* rgba_host);
+/* How many pixels of a device-resident frame have a non-finite R, G or B (a poisoned running mean: see "Numerical contract"
+ * above -- the reference's 0/0 in misMixWeight, P5/fsh:754-757, is reproduced, and a caller who wants to know which frames
+ * carry such pixels need not copy the frame to the host and scan it).  One small kernel on `stream` + a synchronising
+ * 8-byte copy; frame_dev may be any RGBA32F [height][width][4] device buffer (ezrt_render_device's accum_rgba_dev). */
+int ezrt_frame_nonfinite(const float* frame_dev, int width, int height, void* stream, int64_t* n_pixels);
 
 /* Parity audit: render exactly one frame (p->frame0, spp ignored) and report
  * for every pixel of the rect and every ray slot of its path the hit triangle
@@ -159,7 +164,7 @@ int ezrt_tonemap(const float* rgba, int n_pixels, uint8_t* rgb8);
  * sobol(d, grayCode(index0+i)), d < n_dims <= 16 (dimensions 8-15: see ezrt_scene_set_sampler). */
 int ezrt_sobol(uint32_t index0, int n, int n_dims, float* out);
 
-/* Schedule knobs of the implementation ("packet", "leaf_threshold", "megakernel", ... -- listed in
+/* Schedule knobs of the implementation ("leaf_threshold", "refill_min", "megakernel", ... -- listed in
  * DESIGN.md).  They change how the work is scheduled on the GPU, never the results; unknown names
  * are an error.  The oracle accepts and ignores every name. */
 int ezrt_set_option(EzrtScene* s, const char* name, int value);

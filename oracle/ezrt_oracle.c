@@ -1039,6 +1039,19 @@ int ezrt_frame_write(float* frame_dev, int width, int height, const float* rgba_
   return 0;
 }
 
+int ezrt_frame_nonfinite(const float* frame_dev, int width, int height, void* stream, int64_t* n_pixels) {
+  (void)stream;
+  if (!frame_dev || !n_pixels || width <= 0 || height <= 0) return fail(EZRT_ERR_INVALID, "bad frame arguments");
+  int64_t n = 0;
+  for (size_t i = 0; i < (size_t)width * height; i++) { /* non-finite = exponent all ones */
+    uint32_t u[3];
+    memcpy(u, frame_dev + 4 * i, sizeof u);
+    n += ((u[0] & 0x7f800000u) == 0x7f800000u) || ((u[1] & 0x7f800000u) == 0x7f800000u) || ((u[2] & 0x7f800000u) == 0x7f800000u);
+  }
+  *n_pixels = n;
+  return 0;
+}
+
 int ezrt_render_paths(EzrtScene* s, const EzrtRenderParams* p, int32_t* tri_id, float* t_hit, float* colour) {
   if (!s || !tri_id || !t_hit) return fail(EZRT_ERR_INVALID, "NULL argument");
   int rc = validate_params(p);

@@ -58,6 +58,54 @@ def test_c5_full_frame_equals_the_oracle(hip, oracle, c5):
     assert np.isfinite(want[..., :3]).mean() > 0.999 and float(want[..., :3][np.isfinite(want[..., :3])].max()) > 0.5
 
 
+@pytest.fixture(scope="module")
+def c2():
+    return scenes.bunny_scene(subdiv=2, hdr="shipped")
+
+
+def _full_frame_at_baseline_spp(hip, oracle, built, name, spp):
+    """A COMPLETE frame of a BASELINE config at the stated spp: every pixel of libezrt_hip.so's frame against the CPU oracle's,
+    on the bits (NaN == NaN), and the library's own count of non-finite pixels (ezrt_frame_nonfinite) against numpy's."""
+    import torch
+    cfg = scenes.CONFIGS[name]
+    eye, cam = S.camera(*cfg["camera"])
+    W, H = cfg["width"], cfg["height"]
+    p = trace.make_params(W, H, eye, cam, cfg["integrator"], cfg["max_bounce"], spp=spp)
+    sg = built.upload(hip)
+    acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    sg.render_device(p, acc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    n_bad = hip.frame_nonfinite(acc.data_ptr(), W, H, torch.cuda.current_stream().cuda_stream)
+    got = acc.cpu().numpy()
+    want = built.upload(oracle).render(p)
+    assert _same_up_to_nan_payload(got, want), "%s at %d spp: %d pixels differ" % (name, spp, int((_bits(got) != _bits(want)).any(axis=2).sum()))
+    assert n_bad == int((~np.isfinite(want[..., :3]).all(axis=2)).sum())
+    assert np.isfinite(want[..., :3]).mean() > 0.999 and float(want[..., :3][np.isfinite(want[..., :3])].max()) > 0.5
+    return n_bad
+
+
+def test_c2_complete_frame_at_baseline_spp_equals_the_oracle(hip, oracle, c2):
+    """BASELINE configs[1], the headline workload: 512x512, integrator 50, 4 bounces, 64 spp -- the whole frame (this was a
+    hand-run script, tests/check_config_parity.py; oracle ~1 s on 16 cores)."""
+    assert _full_frame_at_baseline_spp(hip, oracle, c2, "C2", 64) == 0
+
+
+def test_c4_complete_frame_at_baseline_spp_equals_the_oracle(hip, oracle, c4):
+    """BASELINE configs[3]: 1024x1024, integrator 51 (env importance sampling + MIS), 2 bounces, 256 spp -- the whole frame
+    (oracle ~22 s on 16 cores).  Chapter 5's MIS weights can be 0/0, as in the reference: such pixels are NaN on both sides."""
+    _full_frame_at_baseline_spp(hip, oracle, c4, "C4", 256)
+
+
+def test_c3_complete_frame_at_baseline_spp_equals_the_oracle(hip, oracle, c3):
+    """BASELINE configs[2]: 1024x1024, 512 012 triangles, integrator 4, 4 bounces, 128 spp -- the whole frame (oracle ~27 s on 16 cores)."""
+    assert _full_frame_at_baseline_spp(hip, oracle, c3, "C3", 128) == 0
+
+
+def test_c5_complete_frame_at_16_spp_equals_the_oracle(hip, oracle, c5):
+    """BASELINE configs[4]: 2048x2048, 10^6 triangles, integrator 51, 8 bounces -- the whole frame at 16 of its 512 spp (the oracle
+    needs ~38 s per 16 spp on 16 cores; the 512-spp figure is checked on a crop by bench.py's `configs` block)."""
+    _full_frame_at_baseline_spp(hip, oracle, c5, "C5", 16)
+
+
 def test_c3_disney_grid_full_resolution(hip, oracle, c3):
     assert c3.tri.shape[0] == 25 * 20480 + 12
     sg = c3.upload(hip)

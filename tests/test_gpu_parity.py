@@ -236,8 +236,8 @@ def test_eight_bounces_wrap_the_sobol_table(hip, oracle, bunny_small, integ):
 def test_exact_distance_ties_follow_the_reference_visit_order(hip, oracle, bunny_small):
     """Every triangle duplicated (identical copies => every hit is an exact tie in t between two
     triangle ids that usually sit in different leaves).  The winner is decided by the reference's
-    visit order (near child first, ties right-first, strict <): the packet kernel must detect the ties
-    and hand those rays to the per-lane kernel; triangle ids must still equal the oracle's."""
+    visit order (near child first, ties right-first, strict <): the 4-wide kernel orders a tie at the lowest common
+    ancestor of the two leaves (or hands the ray to the in-order kernel); triangle ids must still equal the oracle's."""
     twin = bunny_small.tri[:5300:7].copy()
     twin[:, 21:24] = (0.9, 0.1, 0.1)  # the copy is red: the image shows which twin won each tie
     tri = np.concatenate([bunny_small.tri[:5300:7], twin])
@@ -254,10 +254,12 @@ def test_exact_distance_ties_follow_the_reference_visit_order(hip, oracle, bunny
     eye, cam = S.camera(0, 0, 4)
     p = trace.make_params(128, 128, eye, cam, 50, 3, spp=3)
     io = so.render(p)
-    for packet, budget in ((0, 48), (1, 48), (1, 4), (1, 100000)):
-        sg.set_option("packet", packet)
-        sg.set_option("packet_budget", budget)
-        assert np.array_equal(_bits(sg.render(p)), _bits(io)), (packet, budget)
+    for opts in ({}, {"tie_lca": 0}, {"wide4": 0}, {"prune": 0}):
+        for k, v in opts.items():
+            sg.set_option(k, v)
+        assert np.array_equal(_bits(sg.render(p)), _bits(io)), opts
+        for k in opts:
+            sg.set_option(k, {"tie_lca": 1, "wide4": 1, "prune": 2}[k])
     sg.counters_reset()
     sg.render(p)
     so.counters_reset()
@@ -290,36 +292,30 @@ def test_schedule_knobs_never_change_results(hip, bunny_small):
     for integ, mb in ((51, 2), (50, 3)):
         p = trace.make_params(160, 120, eye, cam, integ, mb, spp=3)
         ref = sg.render(p)
-        for opts in ({"megakernel": 1}, {"packet": 1}, {"packet": 1, "packet_budget": 8}, {"leaf_threshold": 1},
-                     {"leaf_threshold": 64}, {"pool_max": 8}, {"pool_div": 16, "pool_max": 2048}, {"trace_wps": 4},
-                     {"trace_wps": 5}, {"trace_wps": 8}, {"lds_nodes": 0}, {"lds_nodes": 7}, {"steal": 0},
-                     {"scatter": 0}, {"scatter": 5}, {"scatter": 8}, {"static_pct": 0}, {"static_pct": 90},
-                     {"refill_min": 1}, {"refill_min": 64}, {"split_shade": 0}, {"split_shade": 1}, {"split_shade": 2}, {"pipes": 2},
-                     {"pipes": 2, "sub_frames": 1}, {"rel_boxes": 0}, {"wide4": 0}, {"wide4": 0, "steal": 0},
-                     {"wide4": 0, "rel_boxes": 0}, {"tail_stage": 2}, {"tail_stage": 3, "wide4": 0}, {"refill_min": 16},
-                     {"redo_overlap": 0}, {"redo_overlap": 1}, {"redo_overlap": 1, "debug_force_pending": 2}, {"launch_events": 1}, {"chunk_log2": 12}, {"chunk_log2": 16}, {"shade_wgs": 1}, {"shade_wgs": 4096}, {"debug_oom_above": 30000}, {"debug_oom_above": 45000}, {"env_rgbe": 0}, {"env_planes": 0}, {"trace_wps_rel": 0}, {"trace_wps_rel": 5}, {"debug_force_pending": 3}, {"debug_force_pending": 1},
-                     {"debug_force_pending": 5, "redo_overlap": 0}, {"debug_force_pending": 2, "split_shade": 2},
-                     {"debug_force_pending": 7, "split_shade": 1}, {"debug_force_pending": 4, "split_shade": 0},
+        for opts in ({"megakernel": 1}, {"leaf_threshold": 1}, {"leaf_threshold": 64}, {"pool_max": 8},
+                     {"pool_div": 16, "pool_max": 2048}, {"trace_wps": 4}, {"trace_wps": 5}, {"trace_wps": 7}, {"lds_nodes": 0},
+                     {"lds_nodes": 7}, {"steal": 0}, {"scatter": 0}, {"scatter": 5}, {"scatter": 8}, {"static_pct": 0},
+                     {"static_pct": 90}, {"refill_min": 1}, {"refill_min": 64}, {"rel_boxes": 0}, {"wide4": 0},
+                     {"wide4": 0, "steal": 0}, {"wide4": 0, "rel_boxes": 0}, {"refill_min": 16}, {"redo_overlap": 0},
+                     {"redo_overlap": 1}, {"redo_overlap": 1, "debug_force_pending": 2}, {"launch_events": 1},
+                     {"chunk_log2": 12}, {"chunk_log2": 16}, {"shade_wgs": 1}, {"shade_wgs": 4096}, {"debug_oom_above": 30000},
+                     {"debug_oom_above": 45000}, {"env_rgbe": 0}, {"env_planes": 0}, {"trace_wps_rel": 0}, {"trace_wps_rel": 5},
+                     {"debug_force_pending": 3}, {"debug_force_pending": 1}, {"debug_force_pending": 5, "redo_overlap": 0},
                      {"prune": 0}, {"prune": 1}, {"prune": 2}, {"prune": 1, "steal": 0}, {"prune": 2, "debug_stack_cap": 1},
-                     {"prune": 2, "debug_stack_cap": 3, "redo_overlap": 0}, {"prune": 2, "lds_nodes": 0}, {"prune": 1, "trace_wps": 4},
-                     {"prune": 2, "prune_min_records": 1 << 20}, {"gen_primary": 0}, {"gen_primary": 0, "prune": 0},
-                     {"path_stage": 0}, {"path_stage": 3}, {"path_stage": 2, "prune": 0}, {"path_stage": 2, "debug_force_pending": 3},
-                     {"path_stage": 2, "debug_stack_cap": 1}, {"path_stage": 2, "lds_nodes": 0}, {"path_stage": 2, "refill_min": 1},
-                     {"stack_cap": 4}, {"stack_cap": 9, "prune": 2}, {"min_staged": 0}, {"min_staged": 4096}, {"prune_mis": 1},
-                     {"semi": 0}, {"semi": 2}, {"semi": 2, "prune": 0}, {"tie_lca": 0}, {"tie_lca": 0, "semi": 0},
-                     {"anyhit": 0}, {"anyhit": 0, "semi": 0}, {"anyhit": 1, "steal": 0}, {"anyhit": 1, "debug_force_pending": 3},
-                     {"anyhit": 1, "debug_stack_cap": 1}, {"anyhit": 1, "prune": 0},
+                     {"prune": 2, "debug_stack_cap": 3, "redo_overlap": 0}, {"prune": 2, "lds_nodes": 0},
+                     {"prune": 1, "trace_wps": 4}, {"prune": 2, "prune_min_records": 1 << 20}, {"gen_primary": 0},
+                     {"gen_primary": 0, "prune": 0}, {"stack_cap": 4}, {"stack_cap": 9, "prune": 2}, {"min_staged": 0},
+                     {"min_staged": 4096}, {"prune_mis": 1}, {"semi": 0}, {"semi": 2}, {"semi": 2, "prune": 0}, {"tie_lca": 0},
+                     {"tie_lca": 0, "semi": 0}, {"anyhit": 0}, {"anyhit": 0, "semi": 0}, {"anyhit": 1, "steal": 0},
+                     {"anyhit": 1, "debug_force_pending": 3}, {"anyhit": 1, "debug_stack_cap": 1}, {"anyhit": 1, "prune": 0},
                      {"lazy_dir": 0}, {"lazy_dir": 1, "debug_force_pending": 3}, {"refill_min_rel": 0}, {"refill_min_rel": 64},
-                     {"refill_min_rel": 1, "refill_min": 1},
-                     {"pipeline_calls": 0}, {"pipeline_calls": 0, "chunk_log2": 12}, {"pipeline_calls": 2, "chunk_log2": 12},
-                     {"pipeline_calls": 2, "debug_oom_above": 30000}, {"pipeline_calls": 2, "debug_force_pending": 3, "redo_overlap": 1},
-                     {"bounce_scatter": 0}, {"bounce_scatter": 2}, {"bounce_scatter": 2, "debug_force_pending": 3}, {"bounce_scatter": 2, "steal": 0},
-                     {"bounce_scatter": 1, "pool_max": 8}, {"bounce_scatter": 2, "static_pct": 0}, {"bounce_scatter": 2, "chunk_log2": 12},
-                     {"handover": 0}, {"handover": 1, "steal": 0}, {"handover": 1, "debug_force_pending": 3},
-                     {"xsteal": 1}, {"xsteal": 1, "xsteal_min_idle": 1, "xsteal_stock": 64}, {"xsteal": 1, "xsteal_groups": 16},
-                     {"xsteal": 1, "debug_force_pending": 3}, {"xsteal": 1, "steal": 0}, {"xsteal": 1, "bounce_scatter": 2},
-                     {"xsteal": 1, "semi": 2}, {"xsteal": 1, "prune": 1}, {"xsteal": 1, "anyhit": 0}, {"xsteal": 1, "debug_stack_cap": 2},
-                     {"xsteal": 1, "gen_primary": 0}, {"xsteal": 1, "pipeline_calls": 0, "trace_wps_rel": 0}):
+                     {"refill_min_rel": 1, "refill_min": 1}, {"pipeline_calls": 0}, {"pipeline_calls": 0, "chunk_log2": 12},
+                     {"pipeline_calls": 2, "chunk_log2": 12}, {"pipeline_calls": 2, "debug_oom_above": 30000},
+                     {"pipeline_calls": 2, "debug_force_pending": 3, "redo_overlap": 1}, {"bounce_scatter": 0},
+                     {"bounce_scatter": 1}, {"bounce_scatter": 1, "debug_force_pending": 3}, {"bounce_scatter": 1, "steal": 0},
+                     {"bounce_scatter": 1, "pool_max": 8}, {"bounce_scatter": 1, "static_pct": 0},
+                     {"bounce_scatter": 1, "chunk_log2": 12}, {"handover": 0}, {"handover": 1, "steal": 0},
+                     {"handover": 1, "debug_force_pending": 3}):
             s2 = bunny_small.upload(hip)
             for k, v in opts.items():
                 s2.set_option(k, v)
@@ -332,8 +328,8 @@ def test_schedule_knobs_never_change_results(hip, bunny_small):
     with pytest.raises(trace.TraceError, match="render scratch"):
         s3.render(p)
     # values that would hang or corrupt a launch are refused: the documented ranges
-    for k, v in (("pool_max", 0), ("pool_div", 0), ("lds_nodes", -1), ("packet_budget", 0), ("leaf_threshold", 0),
-                 ("leaf_threshold", 65), ("trace_wps", 0), ("tail_stage", -1)):
+    for k, v in (("pool_max", 0), ("pool_div", 0), ("lds_nodes", -1), ("leaf_threshold", 0),
+                 ("leaf_threshold", 65), ("trace_wps", 0), ("bounce_scatter", 2)):
         with pytest.raises(trace.TraceError, match="outside"):
             sg.set_option(k, v)
 
@@ -342,22 +338,17 @@ def test_small_pools_with_several_static_rounds_draw_every_ray(hip, bunny_small)
     """ADVICE r4: under the scattered draw of the bounce stages a whole pool can fall into the padding past the queue's end;
     a wave whose FIRST pool did used to retire although its later static rounds held rays (pool_max 8, static_pct 50 on
     a queue of >= 200 000 rays: static_rounds >= 2).  The frame is large enough for that (786 432 pixel-samples in one
-    chunk) and every schedule must give the default's bits -- also with subtrees stolen across waves (xsteal), which needs
-    launches of this size to publish anything."""
+    chunk) and every schedule must give the default's bits."""
     eye, cam = S.camera(0, 0, 4)
     for integ, mb in ((50, 3), (51, 2)):
         p = trace.make_params(512, 512, eye, cam, integ, mb, spp=3)
         ref = bunny_small.upload(hip).render(p)
         for opts in ({"bounce_scatter": 1, "pool_max": 8, "pipeline_calls": 0, "static_pct": 50},
-                     {"bounce_scatter": 2, "pool_max": 8, "pipeline_calls": 0, "static_pct": 95},
-                     {"bounce_scatter": 2, "pool_max": 8, "pipeline_calls": 0, "static_pct": 50},
+                     {"bounce_scatter": 1, "pool_max": 8, "pipeline_calls": 0, "static_pct": 95},
                      {"bounce_scatter": 1, "pool_div": 8, "pipeline_calls": 0},
-                     {"bounce_scatter": 2, "pool_div": 8, "pipeline_calls": 0, "static_pct": 90},
+                     {"bounce_scatter": 1, "pool_div": 8, "pipeline_calls": 0, "static_pct": 90},
                      {"bounce_scatter": 1, "pool_max": 8, "static_pct_pipelined": 50},
-                     {"bounce_scatter": 1, "pool_max": 16, "pipes": 2, "static_pct": 95},
-                     # cross-wave stealing (knob xsteal, off by default: measured slower) only does anything in launches of this size
-                     {"xsteal": 1}, {"xsteal": 1, "xsteal_min_idle": 8, "xsteal_stock": 128}, {"xsteal": 1, "pipeline_calls": 0},
-                     {"xsteal": 1, "xsteal_groups": 16, "xsteal_min_idle": 1}, {"handover": 0}):
+                     {"bounce_scatter": 1, "pool_max": 16, "static_pct": 95}, {"handover": 0}):
             s2 = bunny_small.upload(hip)
             for k, v in opts.items():
                 s2.set_option(k, v)
