@@ -11,7 +11,7 @@ ARCH ?= gfx950
 
 LIBDIR = ezrt_amd/lib
 HOST_SRC = ezrt_amd/csrc/host/scene.cpp ezrt_amd/csrc/host/hdr.cpp ezrt_amd/csrc/host/p2_query.cpp ezrt_amd/csrc/host/host_c_api.cpp
-HIP_SRC = ezrt_amd/csrc/hip/ezrt_hip.hip ezrt_amd/csrc/hip/ezrt_lbvh.hip ezrt_amd/csrc/hip/ezrt_sahbvh.hip ezrt_amd/csrc/hip/ezrt_mgpu.hip
+HIP_SRC = ezrt_amd/csrc/hip/ezrt_hip.hip ezrt_amd/csrc/hip/ezrt_scene_build.hip ezrt_amd/csrc/hip/ezrt_launch.hip ezrt_amd/csrc/hip/ezrt_lbvh.hip ezrt_amd/csrc/hip/ezrt_sahbvh.hip ezrt_amd/csrc/hip/ezrt_mgpu.hip
 HIP_DEPS = $(wildcard ezrt_amd/csrc/hip/*.h) $(wildcard ezrt_amd/csrc/hip/*.hip) $(wildcard include/*)
 
 # -ffp-contract=off everywhere: the trace's discrete decisions must be

@@ -64,23 +64,31 @@ VALU_ISSUE_PEAK_KERNEL_MIX_T = None
 VALU_ISSUE_PEAK_SOURCE = "constant (profiles/r2/valu_issue_microbench.txt)"
 
 
-def _read_valu_peak():
+def _read_valu_peak(profiles_dir=None):
+    """The MEASURED issue ceiling = the best v_mov_b32 row over ALL recorded microbenchmark logs (profiles/r*/valu_issue_microbench.txt).
+    ADVICE r5: reading only the latest log let a noisy, lower re-measurement (1.031 T in r5 vs 1.086 T in r2, same chip model) inflate
+    the fraction with no kernel change.  Since round 6 `roofline.frac` does not use it at all -- it divides by the NOMINAL figure below,
+    a constant -- and this number is printed beside it as `peak_measured`."""
     global VALU_ISSUE_PEAK_T, VALU_ISSUE_PEAK_KERNEL_MIX_T, VALU_ISSUE_PEAK_SOURCE
+    import glob
     import re
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r5", "valu_issue_microbench.txt")
-    try:
-        rows = open(path).read().splitlines()
-    except OSError:
-        return
-    best = {}
-    for r in rows:
-        m = re.match(r"(.+?)\s+W=(\d+)\s+wall .*? chip ([0-9.]+) T wave-instr/s", r)
-        if m:
-            best[m.group(1).strip()] = max(best.get(m.group(1).strip(), 0.0), float(m.group(3)))
+    base = profiles_dir or os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    best, src = {}, {}
+    for path in sorted(glob.glob(os.path.join(base, "r*", "valu_issue_microbench.txt"))):
+        try:
+            rows = open(path).read().splitlines()
+        except OSError:
+            continue
+        for r in rows:
+            m = re.match(r"(.+?)\s+W=(\d+)\s+wall .*? chip ([0-9.]+) T wave-instr/s", r)
+            if m and float(m.group(3)) > best.get(m.group(1).strip(), 0.0):
+                best[m.group(1).strip()] = float(m.group(3))
+                src[m.group(1).strip()] = os.path.relpath(path, os.path.dirname(base))
     if "v_mov_b32" in best:
         VALU_ISSUE_PEAK_T = best["v_mov_b32"]
-        VALU_ISSUE_PEAK_SOURCE = "profiles/r5/valu_issue_microbench.txt (tools/exp_valu_issue.hip: best v_mov_b32 row)"
-    VALU_ISSUE_PEAK_KERNEL_MIX_T = best.get("traceq4 opcode mix (r5)")
+        VALU_ISSUE_PEAK_SOURCE = "%s (tools/exp_valu_issue.hip: best v_mov_b32 row over all recorded logs)" % src["v_mov_b32"]
+    mix = [v for k, v in best.items() if k.startswith("traceq4 opcode mix")]
+    VALU_ISSUE_PEAK_KERNEL_MIX_T = max(mix) if mix else None
 
 
 _read_valu_peak()
@@ -149,6 +157,20 @@ def physical_roofline(trace_ms_per_step, launches_per_step):
         "source": "%s @ %s" % (path, pm["source_sha"]),
     }
     out["traffic_per_launch"] = int(k["hbm_bytes"] / max(1, launches_per_step))
+    # where the wave-cycles go (MI355X_MICROARCH.md "SQ": WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES, disjoint): parked on an
+    # s_waitcnt (the trace loop has no s_barrier), stalled at issue (of which: the LDS pipe), issuing
+    if k.get("SQ_WAVE_CYCLES"):
+        wc = k["SQ_WAVE_CYCLES"]
+        out["stall_split"] = {"parked_on_s_waitcnt": round(k.get("SQ_WAIT_ANY", 0.0) / wc, 4),
+                              "stalled_at_issue": round(k.get("SQ_WAIT_INST_ANY", 0.0) / wc, 4),
+                              "stalled_at_issue_lds_pipe": round(k["SQ_WAIT_INST_LDS"] / wc, 4) if "SQ_WAIT_INST_LDS" in k else None,
+                              "issuing": round(k.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 4),
+                              "issuing_valu": round(k.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, 4),
+                              "issuing_lds": round(k.get("SQ_ACTIVE_INST_LDS", 0.0) / wc, 4),
+                              "vmem_read_instr_per_valu": round(k.get("SQ_INSTS_VMEM_RD", 0.0) / insts, 4),
+                              "lds_instr_per_valu": round(k.get("SQ_INSTS_LDS", 0.0) / insts, 4),
+                              "note": "fractions of SQ_WAVE_CYCLES, summed over the dominant kernel's launches of a step; the loop has no s_barrier, "
+                                      "so 'parked' is s_waitcnt (vmcnt / lgkmcnt drains of the record, triangle and LDS-stack loads)"}
     if pm.get("all_kernels"):
         out["all_kernels_valu_wave_instr_per_step"] = int(pm["all_kernels"]["valu_wave_instr_per_step"])
     return out, None
@@ -237,7 +259,9 @@ def time_config(name, hip, torch, dev, stream, env, spp_override=0, check=True, 
            "rays": int(rays), "trace_ms": round(trace_ms, 3), "trace_launches": int(n_launch), "gpu_ms_unpipelined_with_launch_events": round(total_ms, 3),
            "scene_build_s": round(t_build, 3), "scene_build": bs.build_stats if isinstance(bs.build_stats, dict) else None,
            "scene_create_s": round(t_create, 3), "first_call_s": round(t_first, 3),
-           "non_finite_pixels": int((~torch.isfinite(frame[..., :3]).all(dim=2)).sum())}
+           "non_finite_pixels": int((~torch.isfinite(frame[..., :3]).all(dim=2)).sum()),
+           "non_finite_pixels_ezrt_frame_nonfinite": hip.frame_nonfinite(frame.data_ptr(), W, H, stream),
+           "roofline": config_roofline(name)}
     if check:
         x0, y0, x1, y1 = CONFIG_CROPS[name]
         ora = load_oracle()
@@ -253,13 +277,56 @@ def time_config(name, hip, torch, dev, stream, env, spp_override=0, check=True, 
     return out
 
 
+def config_roofline(name):
+    """The dominant kernel of a BASELINE config and what bounds it, from the committed rocprofv3 summary of that config
+    (profiles/rN/<cfg>_pmc_summary.json: tools/profile_configs.sh + tools/summarize_config_profile.py; kernels profiled ALONE at the
+    BASELINE spp, counters in separate --pmc passes).  Every fraction has a fixed denominator: VALU issue / 1.2288 T wave-instr/s
+    (nominal), HBM (2 FETCH + WRITE) / 8 TB/s.  A stale stamp (other GPU sources) means nothing is quoted."""
+    from ezrt_amd.srchash import gpu_source_hash
+    sha = gpu_source_hash()
+    for rnd in sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r")), reverse=True):
+        cand = os.path.join(ROOT, "profiles", rnd, "%s_pmc_summary.json" % name.lower())
+        if not os.path.exists(cand):
+            continue
+        pm = json.load(open(cand))
+        if pm.get("source_sha") != sha:
+            return {"note_profile": "profiles/%s/%s_pmc_summary.json: stale (GPU sources changed since it was collected: %s)" % (rnd, name.lower(), sha)}
+        ks = {k: v for k, v in pm["kernels"].items() if v.get("share_of_gpu_time") and "issue_rate_T" in v}
+        if not ks:
+            return None
+        k = max(ks, key=lambda n: ks[n]["share_of_gpu_time"])
+        v = ks[k]
+        fr = {"valu_issue": round(v["issue_rate_T"] / VALU_ISSUE_PEAK_NOMINAL_T, 4), "hbm": v.get("hbm_frac_of_8TBs")}
+        bound = max((b for b in fr if fr[b] is not None), key=lambda b: fr[b])
+        out = {"kernel": "ezd::" + k, "share_of_gpu_time": v["share_of_gpu_time"], "launch_us": v["avg_us"], "bound": bound, "frac": fr[bound],
+               "achieved": v["issue_rate_T"] if bound == "valu_issue" else v.get("hbm_GBs"),
+               "peak": round(VALU_ISSUE_PEAK_NOMINAL_T, 4) if bound == "valu_issue" else HBM_PEAK_GBS,
+               "unit": "T wave-instr/s" if bound == "valu_issue" else "GB/s", "ceilings": fr,
+               "lane_fill": v.get("lane_fill"), "wave_cycles_waiting": v.get("wave_cycles_waiting"), "stall_split": v.get("stall_split"),
+               "traffic": v.get("hbm_bytes_per_dispatch_in_counter_pass"),
+               "hbm_bytes_per_pixel_sample": (pm.get("hbm_bytes_per_pixel_sample") or {}).get("by_kernel", {}).get(k),
+               "hbm_bytes_per_pixel_sample_all_kernels": (pm.get("hbm_bytes_per_pixel_sample") or {}).get("all_kernels"),
+               "source": "profiles/%s/%s_pmc_summary.json @ %s (kernels profiled alone: EZRT_PIPELINE_CALLS=0)" % (rnd, name.lower(), pm["source_sha"])}
+        return out
+    return None
+
+
 def scaling_model(tag, sc, hip, torch, dev, stream, make_p, W, H, tile, shards=(2, 4, 8), reps=3):
     """What an N-GPU strong split of this frame would cost, measured on ONE GPU: shard r of N rendered alone (the tiles rank r
     would own; median of `reps` bursts of 4 back-to-back calls), max over r = the critical path of the render phase; + the pack kernel, the payload
-    over one xGMI link (each peer has its own link to rank 0), and the N - 1 un-permute kernels on rank 0.  RCCL's own
-    launch / protocol latency is NOT measurable here and is left out (stated in the field)."""
+    over one xGMI link (each peer has its own link to rank 0), and the N - 1 un-permute kernels on rank 0.  + RCCL's
+    launch / protocol floor as far as ONE GPU can measure it (profiles/r6/rccl_floor.json, tools/exp_rccl_floor.py: a grouped
+    ncclSend / ncclRecv of the payload to the device itself, pack and un-permute kernels subtracted: 10-15 us; a floor, not the cost of an
+    exchange between distinct devices)."""
     from ezrt_amd import tiles
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    floor_ms, floor_src = 0.0, None
+    try:
+        fl = json.load(open(os.path.join(ROOT, "profiles", "r6", "rccl_floor.json")))["payloads"]
+        floor_ms = max(v["rccl_floor_ms"] for v in fl.values())
+        floor_src = "profiles/r6/rccl_floor.json (max over 0.5 / 2 / 8 MiB payloads of loop-back gather - pack - un-permute)"
+    except (OSError, KeyError, ValueError):
+        pass
 
     def timed(fn, n, burst=1):
         """median over n measurements of `burst` back-to-back calls (ms per call).  Render calls are measured in bursts of 4: the
@@ -288,14 +355,16 @@ def scaling_model(tag, sc, hip, torch, dev, stream, make_p, W, H, tile, shards=(
         unpack = timed(lambda: hip.lib.ezrt_tiles_unpack_device(packed.data_ptr(), *a, 1, n, acc.data_ptr(), stream), 5)
         wire = nfl * 4 / (XGMI_LINK_GBS * 1e9) * 1e3
         crit = max(per)
-        total = crit + pack + wire + (n - 1) * unpack
+        total = crit + pack + wire + floor_ms + (n - 1) * unpack
         out["shards"][str(n)] = {"render_ms_per_shard": [round(x, 4) for x in per], "critical_path_ms": round(crit, 4),
                                  "imbalance_max_over_mean": round(crit / (sum(per) / n), 4),
                                  "pack_ms": round(pack, 4), "wire_ms_at_153GBs": round(wire, 4), "unpack_ms_each": round(unpack, 4),
-                                 "payload_bytes_per_peer": nfl * 4, "predicted_ms": round(total, 4),
+                                 "payload_bytes_per_peer": nfl * 4, "rccl_floor_ms": round(floor_ms, 4), "predicted_ms": round(total, 4),
                                  "predicted_speedup": round(t1 / total, 3), "render_only_speedup": round(t1 / crit, 3)}
+    out["rccl_floor_source"] = floor_src
     out["note"] = ("pack / un-permute figures are host-synchronised single launches (they include ~10-20 us of launch + sync overhead each, "
-                   "i.e. pessimistic); RCCL's launch and protocol latency is not included (not measurable on one GPU)")
+                   "i.e. pessimistic); rccl_floor_ms = what one GPU can measure of RCCL's launch + protocol latency (a loop-back grouped "
+                   "send/receive); an exchange between distinct devices over xGMI has never run here and will cost more")
     return out
 
 
@@ -648,37 +717,44 @@ def main():
         rf = {"kernel": "ezd::traceq4_kernel<6,*> (persistent hitBVH over a ray queue; + redo launches of ezd::traceq_kernel<false,6>)",
               "launch_ms": round(ms_trace / launches, 4), "launches_per_step": launches, "trace_ms_per_step": round(ms_trace, 4)}
         if phys:
-            fr = {"valu_issue": phys["issue_frac"], "hbm": phys["hbm_frac"], "l2": phys["l2_frac"], "lds": phys["lds_frac"]}
+            # every fraction on a FIXED denominator: VALU issue / the guide's nominal 1.2288 T wave-instr/s, HBM / 8 TB/s,
+            # L2 / 34.5 TB/s, LDS / 150 TB/s -- recomputable from profiles/rN/pmc_summary.json + trace_ms_per_step of this line
+            fr = {"valu_issue": phys["issue_frac_of_nominal_peak"], "hbm": phys["hbm_frac"], "l2": phys["l2_frac"], "lds": phys["lds_frac"]}
             bound = max(fr, key=fr.get)
             rf.update({"bound": bound, "achieved": phys["issue_rate_T"] if bound == "valu_issue" else None,
-                       "peak": VALU_ISSUE_PEAK_T, "unit": "T wave-instr/s", "frac": fr[bound],
+                       "peak": round(VALU_ISSUE_PEAK_NOMINAL_T, 4), "unit": "T wave-instr/s", "frac": fr[bound],
                        "peak_measured": VALU_ISSUE_PEAK_T, "peak_nominal": round(VALU_ISSUE_PEAK_NOMINAL_T, 4),
-                       "frac_of_nominal_peak": phys["issue_frac_of_nominal_peak"],
+                       "frac_of_measured_peak": phys["issue_frac"],
+                       "useful_lane_frac": round(phys["issue_frac_of_nominal_peak"] * phys["lane_fill"], 4),
+                       "stall_split": phys.get("stall_split"),
                        "peak_kernel_opcode_mix": VALU_ISSUE_PEAK_KERNEL_MIX_T,
                        "frac_of_kernel_opcode_mix_peak": round(phys["issue_rate_T"] / VALU_ISSUE_PEAK_KERNEL_MIX_T, 4) if VALU_ISSUE_PEAK_KERNEL_MIX_T else None,
                        "regime": "the dominant kernel ALONE: per-launch events, calls one at a time, chunks not overlapped (pairs with "
                                  "value_lone_call, not with value)",
-                       "peak_note": "peak = this chip's measured wave64 issue ceiling: " + VALU_ISSUE_PEAK_SOURCE + "; peak_kernel_opcode_mix = the same "
-                                    "microbenchmark on the timed bounce-stage kernel's static opcode histogram; peak_nominal = 256 CUs x 4 SIMDs x "
-                                    "2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)",
+                       "peak_note": "peak = peak_nominal = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md): a "
+                                    "constant, so the fraction only moves when the kernel does; peak_measured = this chip's measured wave64 issue ceiling: "
+                                    + VALU_ISSUE_PEAK_SOURCE + "; peak_kernel_opcode_mix = the same microbenchmark on the timed bounce-stage kernel's "
+                                    "static opcode histogram; useful_lane_frac = frac x lane_fill = issued lane-instructions / the chip's lane-issue peak",
                        "traffic": phys["traffic_per_launch"], "ceilings": fr, "physical": phys})
             if phys.get("all_kernels_valu_wave_instr_per_step"):
                 # the CHIP over a whole step, every kernel: what overlapping consecutive calls changes (the dominant kernel's own fraction
                 # above is measured with the calls one at a time and does not move)
                 av = phys["all_kernels_valu_wave_instr_per_step"]
                 rf["whole_step"] = {"valu_wave_instr_all_kernels": av,
-                                    "issue_frac_in_the_timed_windows": round(av / (ms_per_step * 1e-3) / 1e12 / VALU_ISSUE_PEAK_T, 4),
-                                    "issue_frac_one_call_at_a_time": round(av / (ms_total * 1e-3) / 1e12 / VALU_ISSUE_PEAK_T, 4),
-                                    "note": "all kernels' VALU wave-instructions per step / step time / %.3f T: ms_per_step of the median window "
-                                            "(calls queued back to back, chunks overlapped) vs the median GPU time of a call between two synchronisations" % VALU_ISSUE_PEAK_T}
+                                    "issue_frac_in_the_timed_windows": round(av / (ms_per_step * 1e-3) / 1e12 / VALU_ISSUE_PEAK_NOMINAL_T, 4),
+                                    "issue_frac_one_call_at_a_time": round(av / (ms_total * 1e-3) / 1e12 / VALU_ISSUE_PEAK_NOMINAL_T, 4),
+                                    "note": "all kernels' VALU wave-instructions per step / step time / %.4f T (nominal): ms_per_step of the median window "
+                                            "(calls queued back to back, chunks overlapped) vs the median GPU time of a call between two synchronisations" % VALU_ISSUE_PEAK_NOMINAL_T}
         else:
-            rf.update({"bound": "valu_issue", "achieved": None, "peak": VALU_ISSUE_PEAK_T, "unit": "T wave-instr/s", "frac": None,
+            rf.update({"bound": "valu_issue", "achieved": None, "peak": round(VALU_ISSUE_PEAK_NOMINAL_T, 4), "unit": "T wave-instr/s", "frac": None,
                        "peak_measured": VALU_ISSUE_PEAK_T, "peak_nominal": round(VALU_ISSUE_PEAK_NOMINAL_T, 4),
                        "traffic": None, "note_profile": why})
         rf["work_rate_vs_hbm"] = {
             "definition": "SURVEY.md 8(d): algorithmic bytes of the reference's unpruned traversal in the reference's record sizes "
-                          "(48 P + 96 I + 72 T + 72 M) / trace time / 8 TB/s.  A WORK-RATE figure, not a roofline: the device layout "
-                          "moves fewer bytes and the scene is cache-resident, so it can exceed 1.",
+                          "(48 P + 96 I + 72 T + 72 M) / trace time / 8 TB/s.  A WORK-RATE figure, not a roofline: the timed kernel walks a "
+                          "4-wide re-tree with results-neutral pruning and compact records and the scene is cache-resident, so the ratio exceeds 1 "
+                          "and north_star's '>= 40 % of HBM roofline' can neither be met nor missed on this definition (VERDICT r5 weak #2); the "
+                          "physical HBM fraction of the same kernel is roofline.ceilings.hbm.",
             "achieved_GBs": round(ach, 2), "peak_GBs": HBM_PEAK_GBS, "ratio": round(ach / HBM_PEAK_GBS, 4),
             "ratio_vs_measured_copy_peak_6290": round(ach / 6290.0, 4),
             "alg_bytes_per_launch": int(bytes_trace // launches), "alg_bytes_per_ray": round(bytes_trace / c["rays"], 1),
@@ -737,6 +813,11 @@ def main():
             sc4.close()
             mdl["predicted_speedup"] = {k: {n: v["shards"][n]["predicted_speedup"] for n in v["shards"]} for k, v in mdl.items() if "shards" in v}
             out["scaling_model"] = mdl
+            # (at the top level too, VERDICT r5 #6: C2 is a 1.7-ms frame whose 1/8 shard is launch floors; C4 -- BASELINE configs[3], the
+            # config BASELINE actually puts on 8 GPUs -- is the one the >= 6x target can be judged on)
+            out["predicted_strong_scaling"] = {"C2_512x512_64spp": mdl["predicted_speedup"].get("C2"), "C4_1024x1024_%dspp" % c4["spp"]: mdl["predicted_speedup"].get("C4"),
+                                               "from": "scaling_model: shard r of N rendered alone on this GPU, max over r + pack + wire at 153 GB/s + "
+                                                       "rccl_floor_ms + (N - 1) un-permutes; no N-GPU node has been available in any round"}
 
         # ---- BASELINE configs[2..4] at their stated spp (VERDICT r3 #1b), each with a crop of the timed frame checked against the oracle
         names = [] if args.configs.strip().lower() in ("", "none") else [x.strip().upper() for x in args.configs.split(",")]

@@ -18,10 +18,9 @@
 // every frame of the chunk.
 #pragma once
 #include "ezrt_device.h"
+#include "ezrt_records.h"
 
 namespace ezd {
-
-constexpr int BLOCK = 256;
 
 // dims 0-7: the shader literal (P5/fsh:351-353); dims 8-15: include/ezrt.h, ezrt_scene_set_sampler
 __constant__ uint32_t c_sobol_v[16 * 32] = {

@@ -44,6 +44,7 @@
 // Everything else (persistent waves, prefetched next ray, batched refill, static + dynamic pools, postponed
 // cooperative leaves, intra-wave stealing with the 64-bit atomicMin merge) is ezrt_traceq.h's schedule.
 #pragma once
+#include "ezrt_records.h"
 #include "ezrt_traceq.h"
 
 namespace ezd {
@@ -54,14 +55,7 @@ namespace ezd {
 // the BB product (equal products: either; +-0 only ever feed comparisons; NaN rows of unused slots stay NaN).
 // v_min/v_max/v_min3 issue at about half the rate of v_mul/v_sub on gfx950 (profiles/r2/valu_issue_microbench.txt): 24 of them
 // per record became 12 integer address operations (round 2: +0.9 % on C2, +2.9 % on C5; the min/max form was removed in round 6).
-// Row order of a record, so that the BB row of an axis lies 64 bytes after its AA row:  AAx AAy AAz ref BBx BBy BBz (pad)
-constexpr int N4_ROW_AA = 0, N4_ROW_BB = 4, N4_ROW_REF = 3;
-constexpr uint32_t REF_EMPTY = 0xfffffffdu; // unused slot of a 4-wide record
-constexpr int N4_FLOAT4 = 8;                // record stride in HBM, float4s (7 used)
-constexpr int N4_LDS_DWORDS = 28;           // record stride in LDS: 112 B; 28 r mod 64 hits 16 distinct bank quads
-constexpr uint32_t REF_NOPRUNE = 0x40000000u; // inner reference (and root4): a triangle without a useful bound lies below this record
-constexpr uint32_t REF_INDEX = 0x00ffffffu;   // ... its record index
-
+// (row order and reference bits: ezrt_records.h)
 struct TraceQ4Args {
   TraceQArgs q;             // queue, pools, counters, redo list, knobs (q.lds_nodes is unused here)
   const float4* inner4;     // 4-wide records, breadth-first

@@ -109,6 +109,8 @@ class Scene:
 
     def set_option(self, name, value):
         self._ck(self._tl.lib.ezrt_set_option(self._h, name.encode(), int(value)))
+        self._options = getattr(self, "_options", {})
+        self._options[name] = int(value)   # (what THIS wrapper set: pipeline_selfcheck restores it)
 
     def set_instrumentation(self, level):
         self._ck(self._tl.lib.ezrt_set_instrumentation(self._h, int(level)))
@@ -126,16 +128,25 @@ class Scene:
         self._ck(self._tl.lib.ezrt_last_render_ms(self._h, C.byref(a), C.byref(b), C.byref(n)))
         return a.value, b.value, n.value
 
-    def pipeline_selfcheck(self, params, accum_ptr, stream=None, calls=6, min_gain=1.0):
+    def pipeline_selfcheck(self, params, accum_ptr, stream=None, calls=6, min_gain=1.01, bursts=3):
         """Is overlapping consecutive calls (option pipeline_calls) actually a gain HERE?  It leans on how the runtime maps streams onto
         hardware queues: in a host with many other streams (torch, RCCL) one of the library's chunk streams can land on the caller's
         queue, where the accumulation's barriers block the next chunk, and the overlap turns into a 1-3 % loss
         (profiles/r4/stream_pressure.txt).  This renders `calls` back-to-back calls of `params` into `accum_ptr`
         (a scratch frame buffer of the caller's: it is overwritten) twice with the knob on and twice with it off, interleaved, each
         burst closed by a synchronisation (ezrt_last_render_ms waits for the last call's end event), and KEEPS the knob on only if
-        the pipelined bursts were at least `min_gain` times as fast; otherwise it is switched off for this scene.  Results never
-        depend on the knob.  Returns {"ms_pipelined", "ms_plain", "gain", "kept"}.  A start-up step for a host that renders many frames."""
+        the pipelined bursts were at least `min_gain` times as fast (default 1.01: a tie is noise, and noise must not decide); otherwise
+        it is switched off for this scene.  A knob the caller had switched OFF (set_option("pipeline_calls", 0) or EZRT_PIPELINE_CALLS=0)
+        is respected: nothing is measured and it stays off; a value the caller had set (1 or 2) is the value restored when the check
+        keeps the overlap.  Results never depend on the knob.  Returns {"ms_pipelined", "ms_plain", "gain", "kept"}.  A start-up
+        step for a host that renders many frames."""
+        import os
         import time
+        prior = getattr(self, "_options", {}).get("pipeline_calls")
+        if prior is None and os.environ.get("EZRT_PIPELINE_CALLS") is not None:
+            prior = int(os.environ["EZRT_PIPELINE_CALLS"])
+        if prior == 0:
+            return {"ms_pipelined": None, "ms_plain": None, "gain": None, "kept": False, "skipped": "pipeline_calls was switched off by the caller"}
 
         def burst(on):
             self.set_option("pipeline_calls", 1 if on else 0)
@@ -148,13 +159,13 @@ class Scene:
             return (time.perf_counter() - t0) * 1e3 / max(1, int(calls))
 
         on_ms, off_ms = [], []
-        for _ in range(2):
+        for _ in range(max(2, int(bursts))):
             on_ms.append(burst(True))
             off_ms.append(burst(False))
         ms_on, ms_off = min(on_ms), min(off_ms)
         gain = ms_off / ms_on if ms_on > 0 else 0.0
         kept = gain >= float(min_gain)
-        self.set_option("pipeline_calls", 1 if kept else 0)
+        self.set_option("pipeline_calls", (prior if prior else 1) if kept else 0)
         return {"ms_pipelined": ms_on, "ms_plain": ms_off, "gain": gain, "kept": kept}
 
     def prune_info(self):

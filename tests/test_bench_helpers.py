@@ -1,5 +1,5 @@
-"""bench.py's host-side helpers that need no GPU: the VALU issue ceiling is read from the round's microbenchmark log
-(profiles/r5/valu_issue_microbench.txt, tools/exp_valu_issue.hip) -- VERDICT r4 #8 -- and the algorithmic-bytes formula is SURVEY 8(d)'s."""
+"""bench.py's host-side helpers that need no GPU: the measured VALU issue ceiling is the best row over every recorded microbenchmark log
+(profiles/r*/valu_issue_microbench.txt, tools/exp_valu_issue.hip), and the algorithmic-bytes formula is SURVEY 8(d)'s."""
 import importlib.util
 import os
 
@@ -13,16 +13,33 @@ def _bench():
     return m
 
 
-def test_the_issue_ceiling_comes_from_the_rounds_microbenchmark_log():
+def test_the_measured_issue_ceiling_is_the_best_row_over_all_recorded_logs(tmp_path):
+    """ADVICE r5: the ceiling used to be the latest log's best v_mov_b32 row, so a noisy, lower re-measurement (1.031 T in r5 after
+    1.086 T in r2) raised the reported fraction with no kernel change.  Now: the maximum over every recorded log -- and the headline
+    `roofline.frac` divides by the NOMINAL constant anyway (VERDICT r5 #4)."""
+    import glob
     b = _bench()
-    rows = open(os.path.join(ROOT, "profiles", "r5", "valu_issue_microbench.txt")).read()
-    assert "v_mov_b32" in rows and "traceq4 opcode mix (r5)" in rows
-    # the best v_mov_b32 row is the ceiling, the kernel's own opcode mix sits below it, both below the nominal 2-cycle rate
-    assert b.VALU_ISSUE_PEAK_SOURCE.startswith("profiles/r5/valu_issue_microbench.txt")
-    assert 0.9 < b.VALU_ISSUE_PEAK_T < b.VALU_ISSUE_PEAK_NOMINAL_T
+    best, mix = 0.0, 0.0
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*", "valu_issue_microbench.txt")):
+        for r in open(path).read().splitlines():
+            if r.startswith("v_mov_b32"):
+                best = max(best, float(r.split(" chip ")[1].split()[0]))
+            if r.startswith("traceq4 opcode mix"):
+                mix = max(mix, float(r.split(" chip ")[1].split()[0]))
+    assert abs(best - b.VALU_ISSUE_PEAK_T) < 1e-9 and best >= 1.086
+    assert abs(mix - b.VALU_ISSUE_PEAK_KERNEL_MIX_T) < 1e-9
+    assert 0.9 < b.VALU_ISSUE_PEAK_T < b.VALU_ISSUE_PEAK_NOMINAL_T and abs(b.VALU_ISSUE_PEAK_NOMINAL_T - 1.2288) < 1e-9
     assert 0.5 < b.VALU_ISSUE_PEAK_KERNEL_MIX_T < b.VALU_ISSUE_PEAK_T
-    best = max(float(r.split(" chip ")[1].split()[0]) for r in rows.splitlines() if r.startswith("v_mov_b32"))
-    assert abs(best - b.VALU_ISSUE_PEAK_T) < 1e-9
+    # a later, LOWER log does not lower the ceiling; a later, higher one raises it
+    for rnd, val in (("r7", 0.9), ("r8", 1.15)):
+        os.makedirs(tmp_path / rnd)
+        (tmp_path / rnd / "valu_issue_microbench.txt").write_text(
+            "v_mov_b32              W=8  wall 0.8 ms  chip %.3f T wave-instr/s  per SIMD 1.0 G wave-instr/s\n" % val)
+    os.makedirs(tmp_path / "r2")
+    (tmp_path / "r2" / "valu_issue_microbench.txt").write_text(
+        "v_mov_b32              W=8  wall 0.8 ms  chip 1.086 T wave-instr/s  per SIMD 1.0 G wave-instr/s\n")
+    b._read_valu_peak(str(tmp_path))
+    assert abs(b.VALU_ISSUE_PEAK_T - 1.15) < 1e-9 and "r8" in b.VALU_ISSUE_PEAK_SOURCE
 
 
 def test_algorithmic_bytes_follow_survey_8d():

@@ -1,4 +1,4 @@
-"""The device's own tree over the REFERENCE'S leaves (ezrt_hip.hip retree_leaves, EZRT_RETREE, default on).
+"""The device's own tree over the REFERENCE'S leaves (ezrt_scene_build.hip retree_leaves, EZRT_RETREE, default on).
 
 For a tame ray and nested boxes the fp32 slab test is monotone, so the reference's hitBVH reaches a leaf iff the leaf's OWN
 box is hit -- the inner nodes do not matter.  The library therefore builds its 4-wide records over a binned-SAH tree of the

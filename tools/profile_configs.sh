@@ -20,7 +20,8 @@ for c in $CFGS; do
   i=0
   for PMC in "FETCH_SIZE" "WRITE_SIZE" \
              "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
-             "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
+             "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
+             "SQ_WAIT_INST_LDS"; do
     i=$((i+1))
     timeout 150 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $O/pmc$i -o p -- $CMD > $O/pmc$i.log 2>&1 || echo "$c: pmc pass $i failed: $PMC"
   done

@@ -65,10 +65,20 @@ def main():
             rate = c["SQ_INSTS_VALU"] / (pd["SQ_INSTS_VALU"] * 1e-9) / 1e12
             e.update({"valu_wave_instr_per_dispatch": int(c["SQ_INSTS_VALU"]), "issue_rate_T": round(rate, 4),
                       "issue_frac_of_measured_peak_1.086": round(rate / 1.086, 4), "issue_frac_of_nominal_peak_1.229": round(rate / 1.2288, 4)})
+            if "SQ_INSTS_SALU" in c:
+                e["salu_per_valu"] = round(c["SQ_INSTS_SALU"] / c["SQ_INSTS_VALU"], 3)
             if "SQ_THREAD_CYCLES_VALU" in c and c["SQ_INSTS_VALU"] > 0:
                 e["lane_fill"] = round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"]), 4)
         if c.get("SQ_WAVE_CYCLES"):
-            e["wave_cycles_waiting"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4)
+            wc = c["SQ_WAVE_CYCLES"]
+            e["wave_cycles_waiting"] = round(c.get("SQ_WAIT_ANY", 0.0) / wc, 4)
+            # (MI355X_MICROARCH.md "SQ": WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES, disjoint; WAIT_INST_LDS is a sub-bucket of
+            # WAIT_INST_ANY and comes from a pass of its own: scaled by that pass's wave cycles is not possible, so it is quoted against this one's)
+            e["stall_split"] = {"parked_on_s_waitcnt_or_barrier": round(c.get("SQ_WAIT_ANY", 0.0) / wc, 4),
+                                "stalled_at_issue": round(c.get("SQ_WAIT_INST_ANY", 0.0) / wc, 4),
+                                "stalled_at_issue_lds_pipe": round(c["SQ_WAIT_INST_LDS"] / wc, 4) if "SQ_WAIT_INST_LDS" in c else None,
+                                "issuing": round(c.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 4),
+                                "issuing_valu": round(c.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, 4)}
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c and pd.get("FETCH_SIZE", 0) > 0:
             hbm = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
             sec = 0.5 * (pd["FETCH_SIZE"] + pd.get("WRITE_SIZE", pd["FETCH_SIZE"])) * 1e-9   # (the two counters come from two passes)
