@@ -711,7 +711,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
         for (size_t i = 0; i < nw; i++)
           if (w[i * 8] && w[i * 8] < t0) t0 = w[i * 8];
         unsigned long long s_it = 0, s_is = 0, s_il = 0, s_ll = 0, s_lr = 0, s_busy = 0, s_rf = 0, s_st = 0;
-        std::vector<double> endt, life, its, rays, startt, exht, after;
+        std::vector<double> endt, life, its, rays, startt, exht, after, maxsp;
         for (size_t i = 0; i < nw; i++)
           if (w[i * 8]) {
             startt.push_back((double)(w[i * 8] - t0) * 0.01);
@@ -729,6 +729,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
             s_ll += (uint32_t)w[i * 8 + 4];
             s_lr += w[i * 8 + 4] >> 32;
             s_busy += (uint32_t)w[i * 8 + 5];
+            maxsp.push_back((double)(w[i * 8 + 5] >> 48));
             s_rf += (uint32_t)w[i * 8 + 6];
             s_st += w[i * 8 + 6] >> 32;
           }
@@ -747,8 +748,8 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
         if (!exht.empty())
           fprintf(stderr, "[ezrt]   queue found empty at us p10 %.1f p50 %.1f p90 %.1f max %.1f | a wave then runs on for us p10 %.1f p50 %.1f p90 %.1f max %.1f\n",
                   pct(exht, 0.1), pct(exht, 0.5), pct(exht, 0.9), pct(exht, 1.0), pct(after, 0.1), pct(after, 0.5), pct(after, 0.9), pct(after, 1.0));
-        fprintf(stderr, "[ezrt]   refill block in %.0f %% of the iterations, steal block in %.0f %%\n",
-                100.0 * (double)s_rf / (double)(s_it ? s_it : 1), 100.0 * (double)s_st / (double)(s_it ? s_it : 1));
+        fprintf(stderr, "[ezrt]   refill block in %.0f %% of the iterations, steal block in %.0f %% | highest stack row used by a wave: p50 %.0f p99 %.0f max %.0f\n",
+                100.0 * (double)s_rf / (double)(s_it ? s_it : 1), 100.0 * (double)s_st / (double)(s_it ? s_it : 1), pct(maxsp, 0.5), pct(maxsp, 0.99), pct(maxsp, 1.0));
       }
       uint32_t dbg[3] = {0, 0, 0};
       HIP_TRY(hipMemcpy(dbg, pp.qcounts.p + 100 + 4 * (b & 3), sizeof dbg, hipMemcpyDeviceToHost));

@@ -324,7 +324,7 @@ EZD void traceq4_body(const TraceQ4Args& A) {
   const unsigned long long t_start = (LOG && a.wave_log) ? wall_clock64() : 0ull;
   unsigned long long t_exhausted = 0ull; // (debug_stages=2) when this wave first found the queue empty
   uint32_t wave_iters = 0, dbg_inner_lanes = 0, dbg_inner_steps = 0, dbg_leaf_lanes = 0, dbg_leaf_rounds = 0, dbg_busy_lanes = 0,
-           dbg_refills = 0, dbg_steals = 0;
+           dbg_refills = 0, dbg_steals = 0, dbg_max_sp = 0;
   for (;;) {
     if (LOG) wave_iters++;
     // ---- refill (batched: wave-wide code for per-lane events)
@@ -640,6 +640,7 @@ EZD void traceq4_body(const TraceQ4Args& A) {
       }
     }
 
+    if (LOG && a.wave_log) dbg_max_sp = dbg_max_sp > (uint32_t)sp ? dbg_max_sp : (uint32_t)sp;
     // ---- leaf phase (hitArray, P5/fsh:238-251): postponed until enough lanes wait at a leaf, or nobody can step
     const bool at_leaf = (int32_t)ref < -3; // bit 31 set, not REF_NONE / REF_DONE / REF_EMPTY
     const unsigned long long lm = ballot(at_leaf);
@@ -712,7 +713,12 @@ EZD void traceq4_body(const TraceQ4Args& A) {
     w[2] = wave_iters | ((unsigned long long)dbg_inner_steps << 32);
     w[3] = rr | ((unsigned long long)dbg_inner_lanes << 32);
     w[4] = dbg_leaf_lanes | ((unsigned long long)dbg_leaf_rounds << 32);
-    w[5] = dbg_busy_lanes;
+    unsigned long long mx = dbg_max_sp; // the highest stack row any lane of the wave reached
+    for (int off = 32; off; off >>= 1) {
+      const unsigned long long o = __shfl_xor(mx, off, 64);
+      mx = o > mx ? o : mx;
+    }
+    w[5] = dbg_busy_lanes | (mx << 48);
     w[6] = dbg_refills | ((unsigned long long)dbg_steals << 32);
     w[7] = t_exhausted;
   }
