@@ -248,6 +248,7 @@ struct Pipe {
   DevBuf<uint32_t> qcounts; // [0..63] path counts per stage, [64..99] trace queue heads, [100..115] debug,
                             // [120] redo count, [121] redo queue head
   DevBuf<uint32_t> redo_slots;
+  DevBuf<uint32_t> ovf;         // traceq4_kernel's spill area of the LDS traversal stacks: [launch lanes][OVF_CAP] (TraceQ4Args::stack_cap)
   DevBuf<uint32_t> qheads;      // traceq reservation counters: [launch slot][TRACE_HEADS][TRACE_HEAD_STRIDE] (QHEADS_WORDS in all; zeroed per chunk)
   DevBuf<float4> inner_rel;     // inner records translated by -eye (primary rays)
   DevBuf<float4> inner4_rel;    // 4-wide records translated by -eye

@@ -169,11 +169,19 @@ void launch_traceq_cfg(EzrtScene* s, const TraceCfg& c, const TraceQArgs& q, boo
 // stack rows of a traceq4 launch: the exact worst case of the slot-order traversal; the nearest-first order (prune 2)
 // has no small bound -- it runs with the same rows as its cap (a ray beyond it goes to the redo list) + three rows of
 // slack, because one step pushes up to three entries before the cap is tested
-int stack_cap4(const EzrtScene* s) { // (prune 2 only: the other modes have no overflow route)
-  const int c = s->tune.stack_cap;
-  return (c > 0 && c < s->stack_need4) ? c : s->stack_need4;
+// (round 6) prune 2: the rows are a RING of stack_cap4 rows -- a power of two, 16 unless the knob stack_cap says less -- + one row of
+// spill counters; entries beyond the ring go to the lane's spill area in global memory (TraceQ4Args::stack_cap), so the launch no
+// longer allocates the exact worst case (C3 23, C5 24 rows) for stacks that use 13-17 rows at most
+constexpr int OVF_CAP = 16; // spilled entries per lane (ring + spill = 32 deep before a ray is handed to the redo list)
+int stack_cap4(const EzrtScene* s) { // (prune 2 only: the other modes run with their exact bound)
+  int want = s->tune.stack_cap > 0 ? s->tune.stack_cap : 16;
+  if (s->tune.debug_stack_cap > 0) want = 4; // (test hook: a tiny ring, and a spill area of 4 (debug_stack_cap - 1) entries)
+  int r = 4;
+  while (r * 2 <= want && r < 32) r *= 2;
+  return r;
 }
-int stack_rows4(const EzrtScene* s) { return prune_mode(s) == 2 ? stack_cap4(s) + 3 : s->stack_need4; }
+int ovf_cap4(const EzrtScene* s) { return s->tune.debug_stack_cap > 0 ? 4 * (s->tune.debug_stack_cap - 1) : OVF_CAP; }
+int stack_rows4(const EzrtScene* s) { return prune_mode(s) == 2 ? stack_cap4(s) + 1 : s->stack_need4; }
 int records_staged4(const EzrtScene* s, int wps) {
   const size_t lds_fixed = (size_t)stack_rows4(s) * BLOCK * sizeof(int) + BLOCK * sizeof(int);
   size_t budget = (size_t)(158 * 1024) / (size_t)(wps > 0 ? wps : 1);
@@ -240,6 +248,8 @@ void launch_traceq4_p(int prune, bool log, int wps, dim3 grid, size_t lds, hipSt
         return;
       }
     }
+    // (the bounce stages at seven waves per SIMD -- 72 VGPRs, 24 spills -- were measured once the ring stack had freed the LDS for a
+    // seventh workgroup: C2 -7 %, C3 -6 %, C4 -4 %, C5 -7 %; profiles/r6/ring_stack_ab.txt)
     if constexpr (HAS_LOG) {
       if (log) {
         hipLaunchKernelGGL((traceq4_kernel<6, REL, true, 2, GEN, SEMI, GS>), grid, block, lds, st, q);
@@ -279,7 +289,8 @@ constexpr size_t QHEADS_WORDS = 81 * QHEAD_SLOT_WORDS; // launch slots of reserv
 // t: the stage's queue arguments as for the binary kernel (knobs already filled); rel: 4-wide records translated by
 // t.origin (or NULL)
 // gen (or NULL): the chunk's stage-0 arguments when the launch generates its primary rays itself (needs rel)
-void fill_traceq4_args(const EzrtScene* s, const TraceCfg& c4, const TraceQArgs& t, const float4* rel, const WfArgs* gen, TraceQ4Args& A) {
+// ovf: the scratch set's spill area of the traversal stacks (Pipe::ovf: [grid lanes][OVF_CAP])
+void fill_traceq4_args(const EzrtScene* s, const TraceCfg& c4, const TraceQArgs& t, const float4* rel, const WfArgs* gen, uint32_t* ovf, TraceQ4Args& A) {
   memset(&A.gen_p, 0, sizeof A.gen_p);
   A.gen_blocks = nullptr;
   A.gen_div_blocks = A.gen_div_sub = make_fastdiv(1u);
@@ -310,7 +321,9 @@ void fill_traceq4_args(const EzrtScene* s, const TraceCfg& c4, const TraceQArgs&
     A.prune_a = s->prune_a;
     A.tri_leaf = (s->tune.tie_lca && s->tri_leaf.p && s->ref_up.p) ? s->tri_leaf.p : nullptr;
     A.ref_up = s->ref_up.p;
-    A.stack_cap = (s->tune.debug_stack_cap > 0 && s->tune.debug_stack_cap < stack_cap4(s)) ? s->tune.debug_stack_cap : stack_cap4(s);
+    A.stack_cap = stack_cap4(s);
+    A.ovf = ovf;
+    A.ovf_cap = ovf ? ovf_cap4(s) : 0;
   }
   // (the even / odd slots of a two-ray path must stay in one granule: any granule >= 2 slots does)
   // knob bounce_scatter: 1 (default) = queues with one ray per path only.  Measured in the pipeline (profiles/r4/bounce_scatter_ab.txt):
@@ -320,9 +333,9 @@ void fill_traceq4_args(const EzrtScene* s, const TraceCfg& c4, const TraceQArgs&
   A.handover = (s->tune.handover && t.steal) ? 1u : 0u;
   A.steal_bound = s->tune.steal_bound ? 1u : 0u;
 }
-void launch_traceq4_cfg(EzrtScene* s, const TraceCfg& c4, const TraceQArgs& t, const float4* rel, hipStream_t st, const WfArgs* gen = nullptr) {
+void launch_traceq4_cfg(EzrtScene* s, const TraceCfg& c4, const TraceQArgs& t, const float4* rel, hipStream_t st, const WfArgs* gen, uint32_t* ovf) {
   TraceQ4Args A;
-  fill_traceq4_args(s, c4, t, rel, gen, A);
+  fill_traceq4_args(s, c4, t, rel, gen, ovf, A);
   if (rel && gen) launch_traceq4_rel<true, true>(s, c4, A, st);
   else if (rel) launch_traceq4_rel<true, false>(s, c4, A, st);
   else launch_traceq4_rel<false, false>(s, c4, A, st);
@@ -464,6 +477,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     int rc_cu = ensure_num_cus(s);
     if (rc_cu) return rc_cu;
   }
+  HIP_TRY(pp.ovf.ensure((size_t)s->num_cus * 8 * BLOCK * OVF_CAP)); // (spill area of the traversal stacks: at most 8 workgroups per CU)
   auto queue = [&](int k) {
     RayQueue q;
     q.o = pp.rq_o[k].p;
@@ -618,7 +632,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     {
       if (wide) {
         const bool rel = b == 0 && tu.rel_boxes;
-        launch_traceq4_cfg(s, rel ? cfg4_rel : cfg4_abs, t, rel ? pp.inner4_rel.p : nullptr, st, (rel && gen_primary) ? &a : nullptr);
+        launch_traceq4_cfg(s, rel ? cfg4_rel : cfg4_abs, t, rel ? pp.inner4_rel.p : nullptr, st, (rel && gen_primary) ? &a : nullptr, pp.ovf.p);
       }
       else launch_traceq(t);
       if (t.steal || wide) { // rays that met an exact distance tie, or (4-wide) are not tame -- normally none: reference order, plain stores
@@ -1092,7 +1106,10 @@ static int ezrt_query_hits_body(EzrtScene* s, const float* rays, int n_rays, int
     t.force_pending = 0u;
     t.wave_log = nullptr;
     HIP_TRY(hipEventRecord(s->ev_trace[0][0], nullptr));
-    if (wide) launch_traceq4_cfg(s, trace_cfg4(s, rel4 != nullptr), t, rel4, nullptr, nullptr);
+    if (wide) {
+      HIP_TRY(pp.ovf.ensure((size_t)s->num_cus * 8 * BLOCK * OVF_CAP));
+      launch_traceq4_cfg(s, trace_cfg4(s, rel4 != nullptr), t, rel4, nullptr, nullptr, pp.ovf.p);
+    }
     else launch_traceq_cfg(s, cfg, t, false, nullptr);
     if (t.steal || wide) {
       TraceQArgs r = t;

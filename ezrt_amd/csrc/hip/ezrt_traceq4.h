@@ -73,8 +73,16 @@ struct TraceQ4Args {
   const int2* gen_blocks;
   FastDiv gen_div_blocks, gen_div_sub;
   uint32_t gen_scatter, gen_scatter_shift, gen_frame_first;
-  int32_t stack_cap;        // PRUNE == 2: live stack rows beyond which a ray is handed to the redo list (the launch
-                            // allocates stack_cap + 3 rows: one step pushes at most three)
+  // PRUNE == 2 (nearest-first: no small worst-case bound).  Round 6: the LDS rows of a lane are a RING of stack_cap rows (a power of two:
+  // position p lives in row p & (stack_cap - 1)); when fewer than three rows are free after a step -- one step pushes at most three -- the
+  // lane's OLDEST (up to four) entries move to its spill area in global memory (ovf: ovf_cap entries per lane) and come back, last in first out, when
+  // the ring runs empty; only a lane whose spill area is full too hands its ray to the redo list.  Why: the launch used to allocate the
+  // exact worst case of the slot-order traversal + 3 rows (C2 19, C3 23, C5 24 KB of LDS per workgroup) while the per-wave logs show rays
+  // using 13-17 rows at most (profiles/r6/wide8_pairs_negative.txt "highest stack row"); 16 rows + a counter row fit a sixth workgroup per CU
+  // on the deep scenes.  Row stack_cap of the lane's column holds the number of spilled entries.
+  int32_t stack_cap;
+  uint32_t* ovf;            // [launch lanes][ovf_cap]
+  int32_t ovf_cap;
   // Queue positions are DRAWN in a scattered order (bounce stages; 0 = off, else the template parameter GS): granules of 8 consecutive slots,
   // logical granule g -> physical granule (g mod 256) * R + g / 256, R = ceil(granules / 256) -- a transpose, so that the 16
   // granules of a wave's pool come from 16 places spread over a sixteenth of the queue instead of from one run of 128 slots.
@@ -238,6 +246,7 @@ EZD void traceq4_body(const TraceQ4Args& A) {
   float4* lds_nodes = reinterpret_cast<float4*>(lds_stack + BLOCK + a.stack_entries * BLOCK);
   const float4* inner = REL ? A.inner4_rel : A.inner4;
   for (int k = threadIdx.x; k < A.lds_nodes4 * 7; k += BLOCK) lds_nodes[k] = inner[(k / 7) * N4_FLOAT4 + (k % 7)];
+  if (PRUNE == 2) stack[A.stack_cap * BLOCK] = 0; // (the lane's count of spilled stack entries: TraceQ4Args::stack_cap)
   __syncthreads();
 
   // queue indices: see ezrt_traceq.h
@@ -282,10 +291,26 @@ EZD void traceq4_body(const TraceQ4Args& A) {
     // contributions of a split ray cannot replace it; the redo launch overwrites it with a plain store
     atomicMin(&hits64[s], (unsigned long long)(uint32_t)HIT_PENDING);
   };
+  constexpr bool RING = PRUNE == 2; // (the slot-order modes keep their exact bound and absolute rows)
+  const int ring_mask = RING ? A.stack_cap - 1 : -1; // (-1: p & -1 = p)
   auto finish = [&]() {
     ref = REF_DONE;
     sp = 0;
     sb = 0;
+    if (RING) stack[A.stack_cap * BLOCK] = 0; // (nothing spilled: an early end -- any-hit, the redo list -- may leave entries behind)
+  };
+  // the next pending subtree of this lane's ray, or the end of the ray
+  auto pop_or_finish = [&]() {
+    if (sp > sb) {
+      sp--;
+      ref = (uint32_t)stack[(sp & ring_mask) * BLOCK];
+    } else if (RING && stack[A.stack_cap * BLOCK] > 0) { // (rare) entries spilled to global memory come back, last in first out
+      const int g = stack[A.stack_cap * BLOCK] - 1;
+      ref = A.ovf[(size_t)(blockIdx.x * BLOCK + threadIdx.x) * (uint32_t)A.ovf_cap + (uint32_t)g];
+      stack[A.stack_cap * BLOCK] = g;
+    } else {
+      finish();
+    }
   };
   auto publish = [&]() {
     if (tie_tri >= 0) { // two candidates at the final distance: the reference keeps the one it finds first
@@ -461,7 +486,7 @@ EZD void traceq4_body(const TraceQ4Args& A) {
           int give = 0;
           if (victim) {
             wsrc[vr] = lane;
-            give = stack[sb * BLOCK];
+            give = stack[(sb & ring_mask) * BLOCK];
             sb++;
             if (!shared) atomicExch(&hits64[slot], ~0ull); // first split: "no hit yet" (see ezrt_traceq.h)
             shared = true;
@@ -585,35 +610,41 @@ EZD void traceq4_body(const TraceQ4Args& A) {
         const bool s2 = !s0 && !s1 && h2 && k2 == km;
         const bool s3 = !s0 && !s1 && !s2 && h3;
         if (h3 && !s3) {
-          stack[sp * BLOCK] = (int)r3;
+          stack[(sp & ring_mask) * BLOCK] = (int)r3;
           sp++;
         }
         if (h2 && !s2) {
-          stack[sp * BLOCK] = (int)r2;
+          stack[(sp & ring_mask) * BLOCK] = (int)r2;
           sp++;
         }
         if (h1 && !s1) {
-          stack[sp * BLOCK] = (int)r1;
+          stack[(sp & ring_mask) * BLOCK] = (int)r1;
           sp++;
         }
         if (h0 && !s0) {
-          stack[sp * BLOCK] = (int)r0;
+          stack[(sp & ring_mask) * BLOCK] = (int)r0;
           sp++;
         }
         if (h0 || h1 || h2 || h3) {
           ref = s0 ? r0 : (s1 ? r1 : (s2 ? r2 : r3));
-          // this order has no small worst-case stack bound (up to three pending entries per level): a ray that would
-          // need more rows than the launch has is handed to the redo list (in-order binary kernel, any depth <= 63)
-          // (sp, not sp - sb: rows are addressed absolutely, and a thief taking the bottom row does not move the top)
-          if (sp > A.stack_cap) {
-            tie = true;
-            finish();
+          // this order has no small worst-case stack bound (up to three pending entries per level): when the ring has fewer than
+          // three free rows left the oldest four entries are spilled (TraceQ4Args::stack_cap); a lane whose spill area is full as
+          // well hands its ray to the redo list (in-order binary kernel, any depth <= 63)
+          if (sp - sb > A.stack_cap - 3) {
+            const int g = stack[A.stack_cap * BLOCK];
+            const int live = sp - sb, n_ev = live - 1 < 4 ? live - 1 : 4; // (live >= 2 here; a ring of 4 rows -- the test hook -- keeps one)
+            if (g + n_ev > A.ovf_cap) {
+              tie = true;
+              finish();
+            } else {
+              uint32_t* o = A.ovf + (size_t)(blockIdx.x * BLOCK + threadIdx.x) * (uint32_t)A.ovf_cap + (uint32_t)g;
+              for (int e = 0; e < n_ev; e++) o[e] = (uint32_t)stack[((sb + e) & ring_mask) * BLOCK];
+              sb += n_ev;
+              stack[A.stack_cap * BLOCK] = g + n_ev;
+            }
           }
-        } else if (sp > sb) {
-          sp--;
-          ref = (uint32_t)stack[sp * BLOCK];
         } else {
-          finish();
+          pop_or_finish();
         }
       } else {
       // visit the hit slots in ascending order: continue with the lowest, push the others highest-first
@@ -631,11 +662,8 @@ EZD void traceq4_body(const TraceQ4Args& A) {
       }
       if (h0 || h1 || h2 || h3) {
         ref = h0 ? r0 : (h1 ? r1 : (h2 ? r2 : r3));
-      } else if (sp > sb) {
-        sp--;
-        ref = (uint32_t)stack[sp * BLOCK];
       } else {
-        finish();
+        pop_or_finish();
       }
       }
     }
@@ -693,12 +721,8 @@ EZD void traceq4_body(const TraceQ4Args& A) {
           }
         }
         if (at_leaf) {
-          if (sp > sb && !(anyhit && best_tri >= 0)) {
-            sp--;
-            ref = (uint32_t)stack[sp * BLOCK];
-          } else {
-            finish(); // (an env shadow ray that has hit something is done: only isHit is asked of it)
-          }
+          if (anyhit && best_tri >= 0) finish(); // (an env shadow ray that has hit something is done: only isHit is asked of it)
+          else pop_or_finish();
         }
       }
     }
