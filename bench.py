@@ -322,7 +322,7 @@ def scaling_model(tag, sc, hip, torch, dev, stream, make_p, W, H, tile, shards=(
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     floor_ms, floor_src = 0.0, None
     try:
-        fl = json.load(open(os.path.join(ROOT, "profiles", "r6", "rccl_floor.json")))["payloads"]
+        fl = json.loads([ln for ln in open(os.path.join(ROOT, "profiles", "r6", "rccl_floor.json")).read().splitlines() if ln.startswith("{")][-1])["payloads"]
         floor_ms = max(v["rccl_floor_ms"] for v in fl.values())
         floor_src = "profiles/r6/rccl_floor.json (max over 0.5 / 2 / 8 MiB payloads of loop-back gather - pack - un-permute)"
     except (OSError, KeyError, ValueError):

@@ -48,3 +48,15 @@ def test_algorithmic_bytes_follow_survey_8d():
     base = 48 * 10 + 96 * 7 + 72 * 5 + 72 * 2 + 32 * 3
     assert b.alg_bytes(c, bilinear=True) == base + 48 * 5      # four texels of 12 B per bilinear lookup
     assert b.alg_bytes(c, bilinear=False) == base + 12 * 5
+
+
+def test_the_rccl_floor_file_the_scaling_model_reads_is_parseable():
+    """profiles/r6/rccl_floor.json (tools/exp_rccl_floor.py; RCCL prints a version banner to stdout in front of the JSON line, which the
+    first committed copy still carried -- and bench.py's reader then fell back to a floor of 0 silently): one JSON line with the three
+    payloads, every floor a few microseconds."""
+    import json
+    lines = open(os.path.join(ROOT, "profiles", "r6", "rccl_floor.json")).read().splitlines()
+    d = json.loads([ln for ln in lines if ln.startswith("{")][-1])
+    assert set(d["payloads"]) == {"0.5MiB", "2MiB", "8MiB"}
+    for v in d["payloads"].values():
+        assert 0.001 < v["rccl_floor_ms"] < 0.1 and v["mgpu_rccl_loopback_gather_ms"]["median"] > v["rccl_floor_ms"]
