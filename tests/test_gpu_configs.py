@@ -106,6 +106,23 @@ def test_c5_complete_frame_at_16_spp_equals_the_oracle(hip, oracle, c5):
     _full_frame_at_baseline_spp(hip, oracle, c5, "C5", 16)
 
 
+def test_ring_stack_spills_do_not_change_a_deep_scene(hip, c5):
+    """Round 6: traceq4_kernel's LDS traversal stack is a ring of 16 rows per lane whose oldest entries spill to global memory
+    (TraceQ4Args::stack_cap).  On the 10^6-triangle scene -- the deepest tree of the BASELINE configs: rays use up to 17 rows -- a ring
+    of 4 rows (every ray spills, most of them repeatedly), a ring of 8, and a ring of 4 with a spill area of 4 entries (spills AND
+    hand-overs to the redo list) must give the default's frame on the bits: 8 bounces, env shadow rays, zero-component rays and all."""
+    cfg = scenes.CONFIGS["C5"]
+    eye, cam = S.camera(*cfg["camera"])
+    p = trace.make_params(cfg["width"], cfg["height"], eye, cam, cfg["integrator"], cfg["max_bounce"], spp=2, rect=(896, 1024, 1152, 1216))
+    want = c5.upload(hip).render(p)
+    assert np.isfinite(want[..., :3]).mean() > 0.99 and float(np.nanmax(want[..., :3])) > 0.5
+    for opts in ({"stack_cap": 4}, {"stack_cap": 8}, {"debug_stack_cap": 2}, {"stack_cap": 32}):
+        sg = c5.upload(hip)
+        for k, v in opts.items():
+            sg.set_option(k, v)
+        assert _same_up_to_nan_payload(sg.render(p), want), opts
+
+
 def test_c3_disney_grid_full_resolution(hip, oracle, c3):
     assert c3.tri.shape[0] == 25 * 20480 + 12
     sg = c3.upload(hip)
