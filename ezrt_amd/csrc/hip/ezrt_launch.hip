@@ -166,9 +166,8 @@ void launch_traceq_cfg(EzrtScene* s, const TraceCfg& c, const TraceQArgs& q, boo
 // waves per SIMD of a traceq4 launch: the primary stage's variant may run one more (trace_wps_rel), but only while
 // that still leaves room for a useful top of the tree in LDS (deep trees need the space for stack rows: C5 and C3
 // would stage ONE record at 7 workgroups per CU and lose 3 %)
-// stack rows of a traceq4 launch: the exact worst case of the slot-order traversal; the nearest-first order (prune 2)
-// has no small bound -- it runs with the same rows as its cap (a ray beyond it goes to the redo list) + three rows of
-// slack, because one step pushes up to three entries before the cap is tested
+// stack rows of a traceq4 launch: the exact worst case of the slot-order traversal (prune 0 / 1); the nearest-first order (prune 2)
+// has no small bound and runs on a ring with a spill area (below)
 // (round 6) prune 2: the rows are a RING of stack_cap4 rows -- a power of two, 16 unless the knob stack_cap says less -- + one row of
 // spill counters; entries beyond the ring go to the lane's spill area in global memory (TraceQ4Args::stack_cap), so the launch no
 // longer allocates the exact worst case (C3 23, C5 24 rows) for stacks that use 13-17 rows at most

@@ -39,7 +39,8 @@
 // never hit, no extra instruction) and ref = REF_EMPTY.  Slots are ordered by ascending stack need of their
 // subtrees; without the nearest-first order (PRUNE < 2) they are visited lowest-first with the others pushed in descending
 // order, which bounds the LDS stack by max_j (pending_j + need_j) -- 16 rows on C2 where the binary traversal needs 18.  The
-// nearest-first order runs with that many rows + 3 and hands a ray that would need more to the redo list.
+// nearest-first order (PRUNE == 2, the default) has no such bound: its rows are a ring of 16 with a spill area in global memory
+// (TraceQ4Args::stack_cap; round 6), and only a lane whose spill area is full hands its ray to the redo list.
 //
 // Everything else (persistent waves, prefetched next ray, batched refill, static + dynamic pools, postponed
 // cooperative leaves, intra-wave stealing with the 64-bit atomicMin merge) is ezrt_traceq.h's schedule.

@@ -537,7 +537,7 @@ EZD void shade_emit(const WfArgs& a, const ShadeOut& o, uint32_t* alloc_lds) {
   shade_store<MIS, FORM>(a, o, k);
 }
 
-// Split shading (split_shade): most paths of a stage leave the scene, and everything a leaving path
+// Split shading (the two big stages of the timed route: ezrt_launch.hip launch_shade): most paths of a stage leave the scene, and everything a leaving path
 // needs (state loads, environment lookup, sample store) fits in 45 registers -- so that part runs as
 // its own kernel at twice the occupancy of the full shading kernel, and lists the paths with a surface
 // interaction, which a second kernel then shades in dense waves.  The list is per workgroup (workgroup
