@@ -32,9 +32,7 @@ void ezrt_scene_destroy(EzrtScene* s) {
   if (s->ev_begin) (void)hipEventDestroy(s->ev_begin);
   if (s->ev_end) (void)hipEventDestroy(s->ev_end);
   for (Pipe& q : s->pipe) {
-    if (q.side) ezh::stream_park(q.side, true, q.stream_device); // (q.stream is the device's shared pair: released below, not parked)
-    if (q.ev_main) (void)hipEventDestroy(q.ev_main);
-    if (q.ev_redo) (void)hipEventDestroy(q.ev_redo);
+    // (q.stream is the device's shared pair: released below, not parked)
     if (q.ev_done) (void)hipEventDestroy(q.ev_done);
     if (q.ev_free) (void)hipEventDestroy(q.ev_free);
   }

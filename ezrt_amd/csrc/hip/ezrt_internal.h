@@ -111,11 +111,6 @@ struct Tuning {
                            // binary traceq_kernel.  Instrumented runs (level 1) and scenes whose boxes are not
                            // nested always use the binary kernel.
   int debug_stages = 0;    // print per-stage queue sizes (synchronises)
-  int redo_overlap = 0;    // 1: the redo launch of a stage (exact ties beyond two candidates, rays that are not tame, stack overflows) runs on a
-                           // side stream under the stage's first shading pass and the second pass waits for it; 0 (default since round 3):
-                           // in line, before any shading.  The lists are EMPTY on the BASELINE configs since ties and zero-component rays
-                           // stay in the 4-wide kernel, an empty launch is ~4 us, and the two measure the same (C2 / C4 / C5 within 0.3 %)
-                           // -- without a cross-stream event wait in every frame (ezrt_streams.h: those can enter a slow state)
   int debug_oom_above = 0;     // test hook: chunk scratch for more than this many pixel-samples is reported as out of memory (exercises the
                                // smaller-chunk retry of ezrt_render_device)
   int debug_force_pending = 0; // test hook: every k-th ray slot takes the not-tame route (HIT_PENDING -> redo -> second pass)
@@ -198,7 +193,6 @@ const TuningName kTuning[] = {{"megakernel", &Tuning::megakernel, 0, 1},
                               {"launch_events", &Tuning::launch_events, 0, 1},
                               {"shade_wgs", &Tuning::shade_wgs, 0, 4096},
                               {"chunk_log2", &Tuning::chunk_log2, 12, 28},
-                              {"redo_overlap", &Tuning::redo_overlap, 0, 1},
                               {"debug_force_pending", &Tuning::debug_force_pending, 0, 1 << 20},
                               {"debug_oom_above", &Tuning::debug_oom_above, 0, 1 << 30},
                               {"gen_primary", &Tuning::gen_primary, 0, 1},
@@ -254,10 +248,7 @@ struct Pipe {
   DevBuf<float4> inner4_rel;    // 4-wide records translated by -eye
   DevBuf<uint4> defer_list;     // split shading: paths with a surface interaction, per workgroup
   DevBuf<uint32_t> defer_count;
-  int stream_device = 0;         // device `stream` and `side` belong to (they return to its pool)
-  hipStream_t side = nullptr;    // redo launches that overlap the first shading pass
-  hipEvent_t ev_main = nullptr;  // a stage's main trace launch is enqueued / done
-  hipEvent_t ev_redo = nullptr;  // ... its redo launch is done
+  int stream_device = 0;         // device `stream` belongs to
   hipStream_t stream = nullptr;  // own stream (pipelined calls only)
   hipEvent_t ev_done = nullptr;  // samples of the sub-chunk are complete
   hipEvent_t ev_free = nullptr;  // ... and have been folded into the frame buffer

@@ -96,9 +96,6 @@ int ensure_events(EzrtScene* s) {
     }
   }
   for (Pipe& q : s->pipe) {
-    // (the side stream of the redo launches -- knob redo_overlap, off by default -- is taken from the pool when first needed)
-    if (!q.ev_main) HIP_TRY(hipEventCreateWithFlags(&q.ev_main, hipEventDisableTiming));
-    if (!q.ev_redo) HIP_TRY(hipEventCreateWithFlags(&q.ev_redo, hipEventDisableTiming));
     if (!q.ev_done) HIP_TRY(hipEventCreateWithFlags(&q.ev_done, hipEventDisableTiming));
     if (!q.ev_free) HIP_TRY(hipEventCreateWithFlags(&q.ev_free, hipEventDisableTiming));
   }
@@ -180,7 +177,11 @@ int stack_cap4(const EzrtScene* s) { // (prune 2 only: the other modes run with 
   return r;
 }
 int ovf_cap4(const EzrtScene* s) { return s->tune.debug_stack_cap > 0 ? 4 * (s->tune.debug_stack_cap - 1) : OVF_CAP; }
-int stack_rows4(const EzrtScene* s) { return prune_mode(s) == 2 ? stack_cap4(s) + 1 : s->stack_need4; }
+int stack_rows4(const EzrtScene* s) {
+  if (prune_mode(s) != 2) return s->stack_need4;
+  // (knob prune_mis != 2: the two-ray launches then run a slot-order instance on ABSOLUTE rows -- they need the exact bound too)
+  return s->tune.prune_mis != 2 ? std::max(stack_cap4(s) + 1, s->stack_need4) : stack_cap4(s) + 1;
+}
 int records_staged4(const EzrtScene* s, int wps) {
   const size_t lds_fixed = (size_t)stack_rows4(s) * BLOCK * sizeof(int) + BLOCK * sizeof(int);
   size_t budget = (size_t)(158 * 1024) / (size_t)(wps > 0 ? wps : 1);
@@ -375,39 +376,27 @@ void launch_shade_fused_i(const WfArgs& a, bool full, dim3 grid, hipStream_t st)
     hipLaunchKernelGGL((shade_kernel<INTEG, false, 2>), grid, dim3(SHADE_BLOCK), 0, st, a); // (bounce >= 2: see launch_shade)
   }
 }
-// `between` (or NULL): an event the second pass waits for -- the stage's redo launch on the side stream
-// Returns the status of the cross-stream wait: if it failed, the second pass was NOT launched (it would read hit records
-// the redo launch is still writing) and the caller fails the render call.
 template <int INTEG, int STAGE>
-hipError_t launch_shade_split_ib(const WfArgs& a, dim3 grid, dim3 grid_hit, hipStream_t st, hipEvent_t between) {
+void launch_shade_split_ib(const WfArgs& a, dim3 grid, dim3 grid_hit, hipStream_t st) {
   hipLaunchKernelGGL((shade_miss_kernel<INTEG, false, STAGE>), grid, dim3(SHADE_BLOCK), 0, st, a);
-  if (between) {
-    const hipError_t e = hipStreamWaitEvent(st, between, 0);
-    if (e != hipSuccess) return e;
-  }
   hipLaunchKernelGGL((shade_hit_kernel<INTEG, false, STAGE>), grid_hit, dim3(SHADE_BLOCK), 0, st, a);
-  return hipSuccess;
 }
 template <int INTEG>
-hipError_t launch_shade_i(const WfArgs& a, bool full, dim3 grid, hipStream_t st, hipEvent_t between) {
-  if (!full && a.bounce == 0) return launch_shade_split_ib<INTEG, 0>(a, grid, grid, st, between);
-  if (!full && a.bounce == 1) return launch_shade_split_ib<INTEG, 1>(a, grid, grid, st, between);
-  if (between) { // (the fused kernel reads every hit record at once: behind the redo launch)
-    const hipError_t e = hipStreamWaitEvent(st, between, 0);
-    if (e != hipSuccess) return e;
-  }
-  launch_shade_fused_i<INTEG>(a, full, grid, st);
-  return hipSuccess;
+void launch_shade_i(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
+  if (!full && a.bounce == 0) launch_shade_split_ib<INTEG, 0>(a, grid, grid, st);
+  else if (!full && a.bounce == 1) launch_shade_split_ib<INTEG, 1>(a, grid, grid, st);
+  else launch_shade_fused_i<INTEG>(a, full, grid, st);
 }
-// whether stage b's shading is the split pair (the caller's redo launch may then overlap the first pass)
-inline bool shade_is_split(bool full, int bounce) { return !full && bounce <= 1; }
-hipError_t launch_shade(const WfArgs& a, bool full, dim3 grid, hipStream_t st, hipEvent_t between) {
+// (The redo launch of a stage -- exact ties beyond two candidates, rays that are not tame, spill areas that ran full: normally EMPTY -- runs in
+// line before any shading.  Until round 6 a knob could put it on a side stream under the first shading pass: the two measured the same, and the
+// cross-stream waits it needed can enter a slow state on this runtime (ezrt_streams.h); removed with its stream and events.)
+void launch_shade(const WfArgs& a, bool full, dim3 grid, hipStream_t st) {
   switch (a.p.integrator) {
-    case EZRT_INTEGRATOR_P3_DIFFUSE: return launch_shade_i<EZRT_INTEGRATOR_P3_DIFFUSE>(a, full, grid, st, between);
-    case EZRT_INTEGRATOR_P4_DISNEY: return launch_shade_i<EZRT_INTEGRATOR_P4_DISNEY>(a, full, grid, st, between);
-    case EZRT_INTEGRATOR_P5_SOBOL: return launch_shade_i<EZRT_INTEGRATOR_P5_SOBOL>(a, full, grid, st, between);
-    case EZRT_INTEGRATOR_P5_MIS_ANISO: return launch_shade_i<EZRT_INTEGRATOR_P5_MIS_ANISO>(a, full, grid, st, between);
-    default: return launch_shade_i<EZRT_INTEGRATOR_P5_MIS>(a, full, grid, st, between);
+    case EZRT_INTEGRATOR_P3_DIFFUSE: launch_shade_i<EZRT_INTEGRATOR_P3_DIFFUSE>(a, full, grid, st); break;
+    case EZRT_INTEGRATOR_P4_DISNEY: launch_shade_i<EZRT_INTEGRATOR_P4_DISNEY>(a, full, grid, st); break;
+    case EZRT_INTEGRATOR_P5_SOBOL: launch_shade_i<EZRT_INTEGRATOR_P5_SOBOL>(a, full, grid, st); break;
+    case EZRT_INTEGRATOR_P5_MIS_ANISO: launch_shade_i<EZRT_INTEGRATOR_P5_MIS_ANISO>(a, full, grid, st); break;
+    default: launch_shade_i<EZRT_INTEGRATOR_P5_MIS>(a, full, grid, st); break;
   }
 }
 
@@ -613,11 +602,6 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
       t.wave_log = pp.wave_log.p;
     }
     auto launch_traceq = [&](const TraceQArgs& q, bool small = false) { launch_traceq_cfg(s, cfg, q, small, st); };
-    const bool split_here = shade_is_split(full, b);
-    // the redo launch under the first shading pass: only where the first pass cannot be misled by a record the redo
-    // launch is still to write -- traceq4_kernel marks those HIT_PENDING -- and only in plain timed runs
-    const bool overlap_redo = wide && split_here && tu.redo_overlap && !full && !plog && !debug_stages;
-    hipEvent_t ev_between = nullptr;
     int e = tu.launch_events ? s->n_trace_events : MAX_TRACE_EVENTS;
     if (e < MAX_TRACE_EVENTS) {
       while (s->n_trace_events_created <= e) { // (calls with more than 64 timed launches: created on first use)
@@ -645,17 +629,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
         r.dbg = nullptr;
         r.wave_log = nullptr;
         r.force_pending = 0u;
-        if (overlap_redo) {
-          // the redo launches are a handful of rays on the critical path of the stage's second shading pass: highest priority
-          if (!pp.side) HIP_TRY(ezh::stream_acquire(true, &pp.side, &pp.stream_device));
-          HIP_TRY(hipEventRecord(pp.ev_main, st));
-          HIP_TRY(hipStreamWaitEvent(pp.side, pp.ev_main, 0));
-          launch_traceq_cfg(s, cfg, r, true, pp.side);
-          HIP_TRY(hipEventRecord(pp.ev_redo, pp.side));
-          ev_between = pp.ev_redo;
-        } else {
-          launch_traceq(r, true);
-        }
+        launch_traceq(r, true);
       }
     }
     if (e < MAX_TRACE_EVENTS) {
@@ -702,7 +676,7 @@ int wavefront_chunk(EzrtScene* s, Pipe& pp, const EzrtRenderParams* p, int nb, u
     a.bounce = b;
     a.defer_list = pp.defer_list.p;
     a.defer_count = pp.defer_count.p;
-    HIP_TRY(launch_shade(a, full, dim3(shade_grid), st, ev_between));
+    launch_shade(a, full, dim3(shade_grid), st);
     if (debug_stages) { // diagnostic only: per-stage queue sizes and counters (synchronises)
       uint32_t q[2] = {0, 0};
       unsigned long long c[EZRT_CTR_COUNT];

@@ -116,7 +116,9 @@ def test_ring_stack_spills_do_not_change_a_deep_scene(hip, c5):
     p = trace.make_params(cfg["width"], cfg["height"], eye, cam, cfg["integrator"], cfg["max_bounce"], spp=2, rect=(896, 1024, 1152, 1216))
     want = c5.upload(hip).render(p)
     assert np.isfinite(want[..., :3]).mean() > 0.99 and float(np.nanmax(want[..., :3])) > 0.5
-    for opts in ({"stack_cap": 4}, {"stack_cap": 8}, {"debug_stack_cap": 2}, {"stack_cap": 32}):
+    # (prune_mis 1 / 0: the two-ray launches run a slot-order instance on ABSOLUTE rows while the scene's other launches use the ring --
+    # the launch must then allocate the slot-order bound, 21 rows here, not the ring's 17)
+    for opts in ({"stack_cap": 4}, {"stack_cap": 8}, {"debug_stack_cap": 2}, {"stack_cap": 32}, {"prune_mis": 1}, {"prune_mis": 0}, {"prune_mis": 1, "stack_cap": 4}):
         sg = c5.upload(hip)
         for k, v in opts.items():
             sg.set_option(k, v)

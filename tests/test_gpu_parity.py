@@ -296,13 +296,13 @@ def test_schedule_knobs_never_change_results(hip, bunny_small):
                      {"pool_div": 16, "pool_max": 2048}, {"trace_wps": 4}, {"trace_wps": 5}, {"trace_wps": 7}, {"lds_nodes": 0},
                      {"lds_nodes": 7}, {"steal": 0}, {"scatter": 0}, {"scatter": 5}, {"scatter": 8}, {"static_pct": 0},
                      {"static_pct": 90}, {"refill_min": 1}, {"refill_min": 64}, {"rel_boxes": 0}, {"wide4": 0},
-                     {"wide4": 0, "steal": 0}, {"wide4": 0, "rel_boxes": 0}, {"refill_min": 16}, {"redo_overlap": 0},
-                     {"redo_overlap": 1}, {"redo_overlap": 1, "debug_force_pending": 2}, {"launch_events": 1},
+                     {"wide4": 0, "steal": 0}, {"wide4": 0, "rel_boxes": 0}, {"refill_min": 16}, 
+                     {"debug_force_pending": 2}, {"launch_events": 1},
                      {"chunk_log2": 12}, {"chunk_log2": 16}, {"shade_wgs": 1}, {"shade_wgs": 4096}, {"debug_oom_above": 30000},
                      {"debug_oom_above": 45000}, {"env_rgbe": 0}, {"env_planes": 0}, {"trace_wps_rel": 0}, {"trace_wps_rel": 5},
-                     {"debug_force_pending": 3}, {"debug_force_pending": 1}, {"debug_force_pending": 5, "redo_overlap": 0},
+                     {"debug_force_pending": 3}, {"debug_force_pending": 1}, {"debug_force_pending": 5},
                      {"prune": 0}, {"prune": 1}, {"prune": 2}, {"prune": 1, "steal": 0}, {"prune": 2, "debug_stack_cap": 1},
-                     {"prune": 2, "debug_stack_cap": 3, "redo_overlap": 0}, {"prune": 2, "lds_nodes": 0},
+                     {"prune": 2, "debug_stack_cap": 3}, {"prune": 2, "lds_nodes": 0},
                      {"prune": 1, "trace_wps": 4}, {"prune": 2, "prune_min_records": 1 << 20}, {"gen_primary": 0},
                      {"gen_primary": 0, "prune": 0}, {"stack_cap": 4}, {"stack_cap": 9, "prune": 2}, {"min_staged": 0},
                      {"min_staged": 4096}, {"prune_mis": 1}, {"semi": 0}, {"semi": 2}, {"semi": 2, "prune": 0}, {"tie_lca": 0},
@@ -311,7 +311,7 @@ def test_schedule_knobs_never_change_results(hip, bunny_small):
                      {"lazy_dir": 0}, {"lazy_dir": 1, "debug_force_pending": 3}, {"refill_min_rel": 0}, {"refill_min_rel": 64},
                      {"refill_min_rel": 1, "refill_min": 1}, {"pipeline_calls": 0}, {"pipeline_calls": 0, "chunk_log2": 12},
                      {"pipeline_calls": 2, "chunk_log2": 12}, {"pipeline_calls": 2, "debug_oom_above": 30000},
-                     {"pipeline_calls": 2, "debug_force_pending": 3, "redo_overlap": 1}, {"bounce_scatter": 0},
+                     {"pipeline_calls": 2, "debug_force_pending": 3}, {"bounce_scatter": 0},
                      {"bounce_scatter": 1}, {"bounce_scatter": 1, "debug_force_pending": 3}, {"bounce_scatter": 1, "steal": 0},
                      {"bounce_scatter": 1, "pool_max": 8}, {"bounce_scatter": 1, "static_pct": 0},
                      {"bounce_scatter": 1, "chunk_log2": 12}, {"handover": 0}, {"handover": 1, "steal": 0},
@@ -552,9 +552,9 @@ def test_rgbe_form_of_the_env_map_is_exact(hip, oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("integ", [3, 4, 50, 51, 52])
 def test_pending_rays_take_the_redo_route_under_the_first_shading_pass(hip, oracle, bunny_small, integ):
-    """Rays traceq4_kernel hands to the redo list without an answer (not tame) are published as HIT_PENDING; the redo
-    launch runs on a side stream under the stage's first shading pass, which defers such paths to the second pass --
-    where they may turn out to be hits OR misses (a miss leaves an empty slot in the next queue).  The test hook sends
+    """Rays traceq4_kernel hands to the redo list without an answer (not tame) are published as HIT_PENDING and re-traced by
+    the stage's redo launch in the reference's order, in line before any shading (until round 6 a knob could run it on a side stream
+    under the first shading pass, which is why the shading passes still know how to defer a pending path).  The test hook sends
     every k-th ray slot that way: images, path logs and ray counts must not change."""
     sg, so = bunny_small.upload(hip), bunny_small.upload(oracle)
     eye, cam = S.camera(25, 10, 4)
@@ -564,7 +564,6 @@ def test_pending_rays_take_the_redo_route_under_the_first_shading_pass(hip, orac
     rays = so.counters()["rays"]
     for k in (1, 2, 3, 11):
         sg.set_option("debug_force_pending", k)
-        sg.set_option("redo_overlap", k & 1)  # (the side-stream route and the in-line one: the default since round 3)
         sg.counters_reset()
         assert np.array_equal(_bits(sg.render(p)), _bits(want)), (integ, k)
         sg.set_option("audit_via_queue", 1)

@@ -5,6 +5,8 @@ cross-stream event waits were slow and its frames took 15-35 % longer."""
 import statistics
 import time
 
+import os
+
 import numpy as np
 import pytest
 import torch  # before the fixture loads libezrt_hip.so: both must resolve the same HIP runtime
@@ -160,6 +162,9 @@ def test_pipeline_selfcheck_measures_the_overlap_and_falls_back_when_it_is_not_t
     sc.render_device(p, want.data_ptr(), st)
     torch.cuda.synchronize()
     r = sc.pipeline_selfcheck(p, scratch.data_ptr(), st, calls=8)
+    if os.environ.get("EZRT_PIPELINE_CALLS") == "0":   # (tools/gpu_suite_routes.sh runs the suite with the knob off: nothing is measured then)
+        assert r["kept"] is False and "skipped" in r
+        return
     assert r["ms_pipelined"] > 0 and r["ms_plain"] > 0 and r["kept"] == (r["gain"] >= 1.01)   # (a tie is noise: it does not keep the knob)
     torch.cuda.synchronize()
     assert torch.equal(scratch.view(torch.int32), want.view(torch.int32))
