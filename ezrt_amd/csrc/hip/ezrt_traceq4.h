@@ -610,30 +610,22 @@ EZD void traceq4_body(const TraceQ4Args& A) {
         const bool s1 = !s0 && h1 && k1 == km;
         const bool s2 = !s0 && !s1 && h2 && k2 == km;
         const bool s3 = !s0 && !s1 && !s2 && h3;
-        if (h3 && !s3) {
-          stack[(sp & ring_mask) * BLOCK] = (int)r3;
-          sp++;
-        }
-        if (h2 && !s2) {
-          stack[(sp & ring_mask) * BLOCK] = (int)r2;
-          sp++;
-        }
-        if (h1 && !s1) {
-          stack[(sp & ring_mask) * BLOCK] = (int)r1;
-          sp++;
-        }
-        if (h0 && !s0) {
-          stack[(sp & ring_mask) * BLOCK] = (int)r0;
-          sp++;
-        }
+        stack[(sp & ring_mask) * BLOCK] = (int)r3; // (written unconditionally -- a row above the top is free: see the eviction threshold -- and
+        sp += (h3 && !s3) ? 1 : 0;                    // kept only when the slot is hit and not the one continued with: no divergent branch per push)
+        stack[(sp & ring_mask) * BLOCK] = (int)r2; // (written unconditionally -- a row above the top is free: see the eviction threshold -- and
+        sp += (h2 && !s2) ? 1 : 0;                    // kept only when the slot is hit and not the one continued with: no divergent branch per push)
+        stack[(sp & ring_mask) * BLOCK] = (int)r1; // (written unconditionally -- a row above the top is free: see the eviction threshold -- and
+        sp += (h1 && !s1) ? 1 : 0;                    // kept only when the slot is hit and not the one continued with: no divergent branch per push)
+        stack[(sp & ring_mask) * BLOCK] = (int)r0; // (written unconditionally -- a row above the top is free: see the eviction threshold -- and
+        sp += (h0 && !s0) ? 1 : 0;                    // kept only when the slot is hit and not the one continued with: no divergent branch per push)
         if (h0 || h1 || h2 || h3) {
           ref = s0 ? r0 : (s1 ? r1 : (s2 ? r2 : r3));
           // this order has no small worst-case stack bound (up to three pending entries per level): when the ring has fewer than
           // three free rows left the oldest four entries are spilled (TraceQ4Args::stack_cap); a lane whose spill area is full as
           // well hands its ray to the redo list (in-order binary kernel, any depth <= 63)
-          if (sp - sb > A.stack_cap - 3) {
+          if (sp - sb > A.stack_cap - 4) { // (four rows free for the next step: three pushes and the unconditional write above them)
             const int g = stack[A.stack_cap * BLOCK];
-            const int live = sp - sb, n_ev = live - 1 < 4 ? live - 1 : 4; // (live >= 2 here; a ring of 4 rows -- the test hook -- keeps one)
+            const int live = sp - sb, n_ev = live < 4 ? live : 4; // (live >= 1 here; a ring of 4 rows -- the test hook -- keeps none)
             if (g + n_ev > A.ovf_cap) {
               tie = true;
               finish();
