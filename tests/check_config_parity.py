@@ -1,6 +1,7 @@
 """tests/check_config_parity.py C4 [spp]: one BASELINE config at its full resolution, product (libezrt_hip.so) against the CPU
-oracle, bit for bit (test infrastructure: loads oracle/libezrt_oracle.so).  The -m gpu tests do this at sizes the oracle
-finishes in seconds; this is the same comparison at full size, run by hand on the GPU box."""
+oracle, bit for bit (test infrastructure: loads oracle/libezrt_oracle.so).  Since round 6 tests/test_gpu_configs.py runs this comparison in the -m gpu suite
+for C2 (64 spp), C3 (128), C4 (256) -- their full BASELINE spp -- and C5 at 16 spp; this script is the same comparison for any spp, run by hand on the GPU box
+(round 6: `C5 512`, the one BASELINE frame too long for the suite -- ~20 min of oracle on 16 cores: profiles/r6/full_frame_parity_c5_512spp.txt)."""
 import ctypes, os, sys, time
 sys.path.insert(0, '.')
 import numpy as np
